@@ -1,0 +1,428 @@
+"""oracle/seq_oracle.py -- TEST INFRASTRUCTURE (oracle "A" driver), never imported by the product.
+
+Python face of the sequential CPU restatement (oracle/reina_seq.c): a `Context` with the
+reference's method set (cythonsim/main.pyx:1746-2101) so the parity tests read like a
+`calc/simulation.py` driver.  Host-level work the reference does in Python stays here:
+intervention dispatch (main.pyx:1880-1960) and the contact-table rebuild (the numpy builder in
+reina_model_amd/contacts.py, proven against the goldens through this oracle).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Pinned: bit-exact per-day state vs tests/golden/*.npz (recorded from the real cythonsim).
+"""
+import ctypes
+import os
+import subprocess
+from datetime import date, timedelta
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libreina_seq.so')
+
+# main.pyx:660-682 (infectiousness profile, day relative to symptom onset)
+INFECTIOUSNESS_OVER_TIME = (
+    (-10, 0.00183), (-9, 0.00280), (-8, 0.00446), (-7, 0.00742), (-6, 0.01291), (-5, 0.02350),
+    (-4, 0.04419), (-3, 0.08247), (-2, 0.14018), (-1, 0.19032), (0, 0.18539), (1, 0.13091),
+    (2, 0.07538), (3, 0.04018), (4, 0.02144), (5, 0.01185), (6, 0.00686), (7, 0.00415),
+    (8, 0.00262), (9, 0.00172), (10, 0.00117),
+)
+DISEASE_PARAMS = (
+    'p_susceptibility', 'p_symptomatic', 'p_severe', 'p_critical', 'p_fatal',
+    'p_hospital_death_no_beds', 'p_icu_death_no_beds', 'p_death_outside_hospital',
+    'p_asymptomatic_infection', 'infectiousness_multiplier', 'mean_incubation_duration',
+    'mean_duration_from_onset_to_death', 'mean_duration_from_onset_to_recovery',
+    'ratio_of_duration_before_hospitalisation', 'ratio_of_duration_in_ward',
+    'p_mask_protects_wearer', 'p_mask_protects_others', 'variants',
+)
+SEVERITY_TO_STR = {0: 'ASYMPTOMATIC', 1: 'MILD', 2: 'SEVERE', 3: 'CRITICAL', 4: 'FATAL'}
+STR_TO_SEVERITY = {v: k for k, v in SEVERITY_TO_STR.items()}
+PROBLEM_TO_STR = {
+    0: 'No problemos', 1: 'Too many infectees', 2: 'Too many contacts',
+    3: 'Hospital accounting failure', 4: 'Negative number of contacts', 5: 'Malloc failure',
+    6: 'Other failure', 7: 'Wrong state', 8: 'Contact probability failure', 9: 'Infectees mismatch',
+}
+PLACES = ('home', 'work', 'school', 'transport', 'leisure', 'other')
+NO_TESTING, ALL_WITH_SYMPTOMS_CT, ALL_WITH_SYMPTOMS, ONLY_SEVERE_SYMPTOMS = 0, 1, 2, 3
+COUNTERS = ('infected', 'detected', 'all_detected', 'all_infected', 'in_ward', 'hospitalized',
+            'in_icu', 'cum_icu', 'dead', 'susceptible', 'recovered', 'vaccinated',
+            'non_hospital_deaths', 'new_infections')
+POP_ATTRS13 = ('susceptible', 'vaccinated', 'infected', 'all_infected', 'detected', 'all_detected',
+               'in_icu', 'cum_icu', 'in_ward', 'dead', 'recovered', 'non_hospital_deaths',
+               'new_infections')
+SAMPLE_KINDS = {'contacts_per_day': 0, 'symptom_severity': 1, 'incubation_period': 2,
+                'illness_period': 3, 'hospitalization_period': 4, 'icu_period': 5,
+                'onset_to_removed_period': 6}
+
+MAX_CLASSES = 16
+N_IOT = 21
+
+
+class SimulationFailed(Exception):
+    pass
+
+
+class _VariantParams(ctypes.Structure):
+    _fields_ = (
+        [(n, ctypes.c_double) for n in (
+            'p_hospital_death_no_beds', 'p_icu_death_no_beds', 'infectiousness_multiplier',
+            'p_asymptomatic_infection', 'mean_incubation_duration',
+            'mean_duration_from_onset_to_death', 'mean_duration_from_onset_to_recovery',
+            'ratio_of_duration_in_ward', 'ratio_of_duration_before_hospitalisation',
+            'p_mask_protects_others', 'p_mask_protects_wearer')]
+        + [(n, ctypes.c_int) for n in ('n_sus', 'n_sym', 'n_sev', 'n_cri', 'n_fat', 'n_doh', 'n_iot')]
+        + [(n, ctypes.c_int * MAX_CLASSES) for n in ('c_sus', 'c_sym', 'c_sev', 'c_cri', 'c_fat', 'c_doh')]
+        + [('c_iot', ctypes.c_int * N_IOT)]
+        + [(n, ctypes.c_double * MAX_CLASSES) for n in ('v_sus', 'v_sym', 'v_sev', 'v_cri', 'v_fat', 'v_doh')]
+        + [('v_iot', ctypes.c_double * N_IOT)]
+    )
+
+
+def build(force=False):
+    """gcc the restatement into oracle/libreina_seq.so (no FMA contraction: the reference's C is
+    built for baseline x86-64, float products must round like numpy's / Cython's)."""
+    src = os.path.join(HERE, 'reina_seq.c')
+    deps = [src, os.path.join(HERE, 'npy_random.h'), os.path.join(HERE, 'npy_ziggurat_tables.h')]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    cmd = ['gcc', '-O2', '-fPIC', '-shared', '-ffp-contract=off', '-fno-fast-math', '-std=gnu11',
+           '-o', LIB_PATH, src, '-lm']
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(LIB_PATH)
+        L.seq_create.restype = ctypes.c_void_p
+        L.seq_create.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.seq_destroy.argtypes = [ctypes.c_void_p]
+        L.seq_set_contact_tables.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 5
+        L.seq_set_testing_mode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+        L.seq_add_beds.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.seq_add_icu_units.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.seq_infect_people.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.seq_infect_weekly.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.seq_start_vaccinating.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        L.seq_iterate.restype = ctypes.c_int
+        L.seq_iterate.argtypes = [ctypes.c_void_p]
+        L.seq_get_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.seq_get_scalars.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.seq_get_daily.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.seq_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.seq_rng_pattern.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+        L.seq_sizeof_variant_params.restype = ctypes.c_int
+        assert L.seq_sizeof_variant_params() == ctypes.sizeof(_VariantParams)
+        _lib = L
+    return _lib
+
+
+def pcg64_seed_words(seed):
+    """Initial (state_hi, state_lo, inc_hi, inc_lo) of numpy's PCG64(seed) (SeedSequence is
+    numpy's; simrandom.pyx:16)."""
+    st = np.random.PCG64(seed).state['state']
+    s, inc = int(st['state']), int(st['inc'])
+    m = (1 << 64) - 1
+    return np.array([s >> 64, s & m, inc >> 64, inc & m], dtype=np.uint64)
+
+
+def legacy_shuffled_indices(seed, n):
+    """np.random.seed(seed); np.random.shuffle(arange(n, int32)) -- simrandom.pyx:15 +
+    main.pyx:1435-1436 (legacy MT19937 stream, frozen by numpy's compatibility policy)."""
+    rs = np.random.RandomState(seed)
+    idx = np.arange(n, dtype=np.int32)
+    rs.shuffle(idx)
+    return idx
+
+
+def rng_pattern(seed, pattern, a=0.0, b=0.0):
+    out = np.empty(len(pattern), dtype=np.float64)
+    words = pcg64_seed_words(seed)
+    lib().seq_rng_pattern(words.ctypes.data, pattern.encode(), len(pattern), a, b, out.ctypes.data)
+    return out
+
+
+def _pairs(x):
+    return [(int(a), float(b)) for a, b in x]
+
+
+def _cv_div(a, b):
+    assert [x[0] for x in a] == [x[0] for x in b]
+    return [(x[0], x[1] / y[1]) for x, y in zip(a, b)]
+
+
+def _fill_cv(vp, tag, pairs, cap=MAX_CLASSES):
+    assert len(pairs) <= cap
+    setattr(vp, 'n_' + tag, len(pairs))
+    c = getattr(vp, 'c_' + tag)
+    v = getattr(vp, 'v_' + tag)
+    for i, (k, val) in enumerate(pairs):
+        c[i] = int(k)
+        v[i] = float(val)
+
+
+def _variant_params(params):
+    """variant_init main.pyx:820-850."""
+    vp = _VariantParams()
+    for n in ('p_hospital_death_no_beds', 'p_icu_death_no_beds', 'infectiousness_multiplier',
+              'p_asymptomatic_infection', 'mean_incubation_duration',
+              'mean_duration_from_onset_to_death', 'mean_duration_from_onset_to_recovery',
+              'ratio_of_duration_in_ward', 'ratio_of_duration_before_hospitalisation',
+              'p_mask_protects_others', 'p_mask_protects_wearer'):
+        setattr(vp, n, float(params[n]))
+    sym = _pairs(params['p_symptomatic'])
+    sev = _pairs(params['p_severe'])
+    cri = _pairs(params['p_critical'])
+    fat = _pairs(params['p_fatal'])
+    _fill_cv(vp, 'sus', _pairs(params['p_susceptibility']))
+    _fill_cv(vp, 'sym', sym)
+    _fill_cv(vp, 'sev', _cv_div(sev, sym))
+    _fill_cv(vp, 'cri', _cv_div(cri, sev))
+    _fill_cv(vp, 'fat', _cv_div(fat, cri))
+    _fill_cv(vp, 'doh', _pairs(params['p_death_outside_hospital']))
+    _fill_cv(vp, 'iot', list(INFECTIOUSNESS_OVER_TIME), cap=N_IOT)
+    return vp
+
+
+class Context:
+    """Sequential oracle with the reference Context's public protocol (main.pyx:1759-2101)."""
+
+    def __init__(self, population_params, healthcare_params, disease_params, start_date,
+                 random_seed=4321):
+        from reina_model_amd.contacts import ContactMatrix  # host table builder (shared, see header)
+        L = lib()
+        population_params = dict(population_params)
+        ipc = population_params.pop('initial_population_condition', None)
+        if ipc is not None and hasattr(ipc, 'has_initial_state') and ipc.has_initial_state():
+            raise NotImplementedError('set_initial_state (main.pyx:1452-1516) is not restated yet')
+        ages = population_params['age_structure']
+        if hasattr(ages, 'items') and hasattr(ages, 'index'):
+            nr_ages = int(ages.index.max()) + 1
+            age_counts = np.zeros(nr_ages, dtype=np.int32)
+            for a, c in ages.items():
+                age_counts[int(a)] = int(c)
+        else:
+            age_counts = np.asarray(ages, dtype=np.int32).copy()
+            nr_ages = len(age_counts)
+        self.nr_ages = nr_ages
+        self.total_people = int(age_counts.sum())
+
+        # Disease.__init__ main.pyx:868-881
+        self.variant_names = ['wild-type']
+        vps = [_variant_params(disease_params)]
+        for variant in disease_params['variants']:
+            vp = dict(disease_params)
+            vp.update(variant)
+            vps.append(_variant_params(vp))
+            self.variant_names.append(variant['name'])
+        self.nr_variants = len(vps)
+        varr = (_VariantParams * len(vps))(*vps)
+
+        # imported_infection_ages main.pyx:1376-1384
+        ages_w = population_params['imported_infection_ages']
+        wsum = sum([x[1] for x in ages_w])
+        total = 0
+        classes, cum = [], []
+        for age, weight in ages_w:
+            weight = weight / wsum
+            classes.append(int(age))
+            cum.append(weight + total)
+            total += weight
+        classes = np.asarray(classes, dtype=np.int32)
+        cum = np.asarray(cum, dtype=np.float64)
+
+        self.age_group_labels = list(population_params['age_groups']['labels'])
+        self.age_group_indices = np.asarray(population_params['age_groups']['age_indices'], dtype=np.int32)
+
+        perm = legacy_shuffled_indices(random_seed, self.total_people)
+        words = pcg64_seed_words(random_seed)
+        self._h = L.seq_create(nr_ages, age_counts.ctypes.data, perm.ctypes.data, words.ctypes.data,
+                               len(vps), ctypes.addressof(varr), len(classes), classes.ctypes.data,
+                               cum.ctypes.data, int(healthcare_params['hospital_beds']),
+                               int(healthcare_params['icu_units']))
+        self.contact_matrix = ContactMatrix(population_params['contacts_per_day'], nr_ages)
+        self._upload_tables()
+        self.start_date = start_date
+        self.day = 0
+        self.interventions = []
+        self._L = L
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._L.seq_destroy(h)
+            self._h = None
+
+    def _upload_tables(self):
+        t = self.contact_matrix.tables
+        lib().seq_set_contact_tables(
+            self._h, t.nr_contacts_by_age.ctypes.data, t.offset.ctypes.data, t.count.ctypes.data,
+            len(t.place), t.place.ctypes.data, t.cmin.ctypes.data, t.cmax.ctypes.data,
+            t.cum_p.ctypes.data, t.mask_p.ctypes.data)
+
+    def get_date_for_today(self):
+        d = date.fromisoformat(self.start_date)
+        return (d + timedelta(days=self.day)).isoformat()
+
+    def add_intervention(self, iv):
+        self.interventions.append(iv)
+
+    def find_variant(self, variant_str):
+        if variant_str is None:
+            return 0
+        for idx, vn in enumerate(self.variant_names):
+            if variant_str == vn:
+                return idx
+        raise Exception('Variant %s not found' % variant_str)
+
+    # main.pyx:1880-1960
+    def apply_intervention(self, iv):
+        L = self._L
+        params = iv.get_param_values()
+        t = iv.type
+        if t == 'test-all-with-symptoms':
+            L.seq_set_testing_mode(self._h, ALL_WITH_SYMPTOMS, 1.0)
+        elif t == 'test-only-severe-symptoms':
+            L.seq_set_testing_mode(self._h, ONLY_SEVERE_SYMPTOMS, params['mild_detection_rate'] / 100.0)
+        elif t == 'test-with-contact-tracing':
+            L.seq_set_testing_mode(self._h, ALL_WITH_SYMPTOMS_CT, params['efficiency'] / 100.0)
+        elif t == 'build-new-icu-units':
+            L.seq_add_icu_units(self._h, int(params['units']))
+        elif t == 'build-new-hospital-beds':
+            L.seq_add_beds(self._h, int(params['beds']))
+        elif t == 'import-infections':
+            L.seq_infect_people(self._h, int(params['amount']), self.find_variant(params.get('variant')))
+        elif t == 'import-infections-weekly':
+            shares = [0] * len(self.variant_names)
+            for pn in params.keys():
+                if not pn.startswith('variant_'):
+                    continue
+                vid = self.find_variant(pn.replace('variant_', ''))
+                share = params[pn]
+                shares[vid] = share / 100 if share else 0
+            shares[0] = 1 - sum(shares)
+            arr = np.asarray(shares, dtype=np.float64)
+            L.seq_infect_weekly(self._h, int(params['weekly_amount']), arr.ctypes.data)
+        elif t == 'limit-mobility':
+            reduction = (100 - params['reduction']) / 100.0
+            place = params.get('place')
+            if place is not None:
+                place = PLACES.index(place)
+            self.contact_matrix.set_mobility_factor(reduction, place=place, min_age=params.get('min_age'),
+                                                    max_age=params.get('max_age'))
+        elif t == 'wear-masks':
+            p = params['share_of_contacts'] / 100.0
+            place = params.get('place')
+            if place is not None:
+                place = PLACES.index(place)
+            self.contact_matrix.set_mask_probability(p, place=place, min_age=params.get('min_age'),
+                                                     max_age=params.get('max_age'))
+        elif t == 'vaccinate':
+            nr = params['weekly_vaccinations'] / 7
+            mn, mx = params.get('min_age'), params.get('max_age')
+            L.seq_start_vaccinating(self._h, float(nr), -1 if mn is None else int(mn),
+                                    -1 if mx is None else int(mx))
+        else:
+            raise Exception()
+
+    # main.pyx:2011-2018
+    def iterate(self):
+        today = self.get_date_for_today()
+        for iv in self.interventions:
+            if iv.date == today:
+                self.apply_intervention(iv)
+        if self.contact_matrix.init_day():
+            self._upload_tables()
+        problem = self._L.seq_iterate(self._h)
+        self.day += 1
+        if problem != 0:
+            raise SimulationFailed(PROBLEM_TO_STR[problem])
+
+    def counters(self):
+        out = np.zeros((len(COUNTERS), self.nr_ages), dtype=np.int32)
+        self._L.seq_get_counters(self._h, out.ctypes.data)
+        return {n: out[i] for i, n in enumerate(COUNTERS)}
+
+    def scalars(self):
+        out = np.zeros(12, dtype=np.int64)
+        self._L.seq_get_scalars(self._h, out.ctypes.data)
+        return out
+
+    # main.pyx:1813-1857
+    def generate_state(self):
+        cnt = self.counters()
+        sc = self.scalars()
+        total_infections, total_infectors = int(sc[4]), int(sc[5])
+        r = total_infections / total_infectors if total_infectors > 5 else 0
+        s = dict(
+            available_icu_units=int(sc[0]), available_hospital_beds=int(sc[1]),
+            total_icu_units=int(sc[2]), r=r, exposed_per_day=int(sc[6]),
+            ct_cases_per_day=int(sc[7]),
+            mobility_limitation=1 - float(self.contact_matrix.mobility_factor),
+        )
+        ngroups = len(self.age_group_labels)
+        for attr in POP_ATTRS13:
+            s[attr] = np.bincount(self.age_group_indices, weights=cnt[attr],
+                                  minlength=ngroups).astype(np.int32)
+        dc = np.zeros(6, dtype=np.int32)
+        ibv = np.zeros(self.nr_variants, dtype=np.int32)
+        self._L.seq_get_daily(self._h, dc.ctypes.data, ibv.ctypes.data)
+        s['infected_by_variant'] = {self.variant_names[i]: int(ibv[i]) for i in range(self.nr_variants)}
+        s['daily_contacts'] = {PLACES[i]: int(dc[i]) for i in range(6)}
+        return s
+
+    def get_population_stats(self, what):
+        if what not in ('dead', 'all_infected', 'all_detected'):
+            raise Exception()
+        return self.counters()[what].copy()
+
+    # main.pyx:2047-2101
+    def sample(self, what, age, severity=None, sample_size=10000):
+        if what not in SAMPLE_KINDS:
+            raise Exception('unknown sample type. supported: %s' % ', '.join(SAMPLE_KINDS))
+        out = np.empty(sample_size, dtype=np.int32)
+        sev = -1 if severity is None else STR_TO_SEVERITY[severity]
+        self._L.seq_sample(self._h, SAMPLE_KINDS[what], int(age), sev, sample_size, out.ctypes.data)
+        return out
+
+
+def create_disease_params(variables):
+    """calc/simulation.py:50-61: percentages -> fractions."""
+    kwargs = {}
+    for key in DISEASE_PARAMS:
+        val = variables[key]
+        if key.startswith('p_') or key.startswith('ratio_'):
+            if isinstance(val, list):
+                val = [(age, sev / 100) for age, sev in val]
+            else:
+                val = val / 100
+        kwargs[key] = val
+    return kwargs
+
+
+def make_context(variables, age_counts, seed, interventions=None):
+    """Build an oracle Context the way calc/simulation.py:148-180 builds the reference's."""
+    from reina_model_amd import datasets
+    from reina_model_amd.interventions import iv_tuple_to_obj
+    age_to_group = datasets.make_age_groups(variables['max_age'])
+    groups = list(np.unique(age_to_group))
+    pop_params = dict(
+        age_structure=np.asarray(age_counts),
+        contacts_per_day=datasets.get_contacts_per_day(variables['country']),
+        age_groups=dict(labels=groups, age_indices=[groups.index(x) for x in age_to_group]),
+        imported_infection_ages=variables['imported_infection_ages'],
+    )
+    hc = dict(hospital_beds=variables['hospital_beds'], icu_units=variables['icu_units'])
+    ctx = Context(pop_params, hc, create_disease_params(variables), variables['start_date'], seed)
+    vnames = tuple(v['name'] for v in variables['variants'])
+    ivs = variables['interventions'] if interventions is None else interventions
+    for iv in ivs:
+        ctx.add_intervention(iv_tuple_to_obj(iv, vnames))
+    return ctx

@@ -1,0 +1,152 @@
+"""Host-side contact matrix: mobility factors, mask probabilities and the sampling tables.
+
+Mirror of the reference's `ContactMatrix` (cythonsim/main.pyx:1119-1288): same methods
+(`set_mobility_factor`, `set_mask_probability`, `init_day`), same table semantics, numpy instead
+of pandas.  The tables it produces are what the device kernels (and the CPU oracles) sample from:
+
+  * ``nr_contacts_by_age[a]``  float64 — total contacts/day of a participant aged ``a`` after the
+    multiplicative mobility factors (main.pyx:1198-1211);
+  * per age, the list of (place, contact_age_min, contact_age_max, cum_p, mask_p) entries in the
+    reference's order — sorted by place-type STRING then contact-age tuple (main.pyx:1213-1235,
+    pandas `sort_index`) — with ``cum_p`` the running sum of contacts/total.
+
+Bit-compat notes (checked end-to-end by the sequential oracle against the cythonsim goldens):
+  * per-age totals follow pandas' groupby-sum, which is a Kahan-compensated sum in row order;
+  * mobility factors and the scalar `mobility_factor` are stored as C floats in the reference
+    (`cdef public float`, main.pyx:1110,1128), i.e. rounded to float32 before use;
+  * `wear-masks` only edits the mask matrix; tables pick it up at the next rebuild (quirk Q4).
+"""
+import numpy as np
+
+PLACES = ('home', 'work', 'school', 'transport', 'leisure', 'other')  # enum order main.pyx:64-70
+PLACE_ALL = 100
+
+
+class ContactTables:
+    """Flat arrays for one rebuild. Entries of age a are [offset[a], offset[a]+count[a])."""
+
+    def __init__(self, nr_contacts_by_age, offset, count, place, cmin, cmax, cum_p, mask_p):
+        self.nr_contacts_by_age = nr_contacts_by_age
+        self.offset = offset
+        self.count = count
+        self.place = place
+        self.cmin = cmin
+        self.cmax = cmax
+        self.cum_p = cum_p
+        self.mask_p = mask_p
+
+
+class ContactMatrix:
+    def __init__(self, contacts_per_day, nr_ages):
+        """contacts_per_day: iterable of (place_type, participant_age, (cmin, cmax), contacts) or a
+        DataFrame with those columns (calc/simulation.py:74-100)."""
+        if hasattr(contacts_per_day, 'itertuples'):
+            rows = [(t.place_type, int(t.participant_age), tuple(t.contact_age), float(t.contacts))
+                    for t in contacts_per_day.itertuples()]
+        else:
+            rows = [(r[0], int(r[1]), tuple(r[2]), float(r[3])) for r in contacts_per_day]
+        self.nr_ages = nr_ages
+        self._place = np.array([PLACES.index(r[0]) for r in rows], dtype=np.int32)
+        self._page = np.array([r[1] for r in rows], dtype=np.int32)
+        self._cmin = np.array([r[2][0] for r in rows], dtype=np.int32)
+        self._cmax = np.array([r[2][1] for r in rows], dtype=np.int32)
+        self._contacts = np.array([r[3] for r in rows], dtype=np.float64)
+        # sort key of the reference's MultiIndex: (place_type string, contact_age tuple)
+        place_rank = {p: i for i, p in enumerate(sorted(PLACES))}
+        self._rank = np.array([place_rank[r[0]] for r in rows], dtype=np.int64)
+        self.mobility_factors = []  # [place, min_age, max_age, factor(float32)]
+        self.mobility_factor = np.float32(1.0)
+        self.mobility_factor_changed = False
+        self.mask_probabilities = np.zeros((nr_ages, len(PLACES)), dtype=np.float64)
+        # per-age row lists in original order
+        self._rows_of_age = [np.nonzero(self._page == a)[0] for a in range(nr_ages)]
+        self.tables = None
+        self.generate_contact_probabilities()
+
+    # main.pyx:1250-1266
+    def set_mobility_factor(self, factor, place=None, min_age=None, max_age=None):
+        factor = np.float32(factor)
+        self.mobility_factor = factor
+        if place is None:
+            place = PLACE_ALL
+        if min_age is None:
+            min_age = 0
+        if max_age is None:
+            max_age = self.nr_ages - 1
+        for mf in self.mobility_factors:
+            if mf[0] == place and mf[1] == min_age and mf[2] == max_age:
+                mf[3] = factor
+                break
+        else:
+            self.mobility_factors.append([place, min_age, max_age, factor])
+        self.mobility_factor_changed = True
+
+    # main.pyx:1268-1283
+    def set_mask_probability(self, p, place=None, min_age=None, max_age=None):
+        if min_age is None:
+            min_age = 0
+        if max_age is None:
+            max_age = self.nr_ages - 1
+        places = list(range(len(PLACES))) if place is None else [place]
+        lo, hi = max(min_age, 0), min(max_age, self.nr_ages - 1)
+        if hi >= lo:
+            for pl in places:
+                self.mask_probabilities[lo:hi + 1, pl] = p
+
+    # main.pyx:1285-1288
+    def init_day(self):
+        """Returns True when the tables were rebuilt (caller re-uploads them)."""
+        if self.mobility_factor_changed:
+            self.generate_contact_probabilities()
+            self.mobility_factor_changed = False
+            return True
+        return False
+
+    # main.pyx:1184-1235
+    def generate_contact_probabilities(self):
+        contacts = self._contacts.copy()
+        for place, min_age, max_age, factor in self.mobility_factors:
+            if factor == 1.0:
+                continue
+            f = (self._page >= min_age) & (self._page <= max_age)
+            if place != PLACE_ALL:
+                f &= self._place == place
+            contacts[f] *= float(factor)
+
+        A = self.nr_ages
+        totals = np.zeros(A, dtype=np.float64)
+        offset = np.zeros(A, dtype=np.int32)
+        count = np.zeros(A, dtype=np.int32)
+        places, cmins, cmaxs, cums, masks = [], [], [], [], []
+        pos = 0
+        for a in range(A):
+            rows = self._rows_of_age[a]
+            c = contacts[rows]
+            # pandas groupby(...).sum(): Kahan summation in row order
+            sumx = 0.0
+            comp = 0.0
+            for v in c.tolist():
+                y = v - comp
+                t = sumx + y
+                comp = t - sumx - y
+                sumx = t
+            totals[a] = sumx
+            # sort_index on (place_type, contact_age); stable w.r.t. original order
+            order = np.lexsort((self._cmax[rows], self._cmin[rows], self._rank[rows]))
+            r = rows[order]
+            with np.errstate(divide='ignore', invalid='ignore'):
+                cum = np.cumsum(contacts[r] / sumx)
+            offset[a] = pos
+            count[a] = len(r)
+            pos += len(r)
+            places.append(self._place[r])
+            cmins.append(self._cmin[r])
+            cmaxs.append(self._cmax[r])
+            cums.append(cum)
+            masks.append(self.mask_probabilities[a, self._place[r]].astype(np.float32))
+        self.tables = ContactTables(
+            totals, offset, count,
+            np.concatenate(places).astype(np.int32), np.concatenate(cmins).astype(np.int32),
+            np.concatenate(cmaxs).astype(np.int32), np.concatenate(cums).astype(np.float64),
+            np.concatenate(masks).astype(np.float32))
+        return self.tables

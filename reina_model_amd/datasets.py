@@ -1,0 +1,67 @@
+"""Input data for the agent engine: age structure and POLYMOD-style contact rows.
+
+Host-side counterpart of the reference loaders `calc/datasets.py:48-79`
+(`get_population_for_area`, `get_contacts_for_country`) and of the long-form expansion in
+`calc/simulation.py:74-100` (`get_contacts_per_day`).  The reference reads CSV/XLS with pandas;
+here the FI rows of its contact matrix and the HUS age histogram ship as one small JSON
+(`data/fi_hus.json`, produced by tests/golden/make_golden.py) and are expanded with plain
+Python so that the row ORDER (which fixes the floating-point summation order of the per-age
+totals, see contacts.py) is identical to the reference's melted DataFrame.
+"""
+import json
+import os
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'fi_hus.json')
+_cache = {}
+
+
+def _load():
+    if 'd' not in _cache:
+        with open(_DATA) as f:
+            _cache['d'] = json.load(f)
+    return _cache['d']
+
+
+def get_population_for_area(area_name='HUS'):
+    """Age histogram int64[A] (index = age). Only the bundled area is available offline."""
+    d = _load()
+    if area_name != d['area_name']:
+        raise KeyError('no bundled population for area %r (have %r)' % (area_name, d['area_name']))
+    return np.asarray(d['age_counts'], dtype=np.int64)
+
+
+def scaled_population(total, base=None):
+    """Synthetic population with the HUS age shape: count[a] = round(base[a] * total / sum(base)),
+    every age keeps >= 1 agent."""
+    base = get_population_for_area() if base is None else np.asarray(base, dtype=np.int64)
+    s = np.round(base * (float(total) / float(base.sum()))).astype(np.int64)
+    return np.maximum(s, 1)
+
+
+def get_contacts_per_day(country='FI'):
+    """Long-form contact rows in the reference's order: for each contact-age column, for each
+    (place, participant group) CSV row, one row per participant age in the group.
+
+    Returns a list of tuples (place_type: str, participant_age: int, (cmin, cmax), contacts: float).
+    """
+    d = _load()
+    if country != d['country']:
+        raise KeyError('no bundled contact matrix for country %r' % country)
+    rows = []
+    for ci, (cmin, cmax) in enumerate(d['contact_groups']):
+        for place, pmin, pmax, vals in d['contact_rows']:
+            c = vals[ci]
+            for p in range(pmin, pmax + 1):
+                rows.append((place, p, (cmin, cmax), c))
+    return rows
+
+
+def make_age_groups(max_age=100):
+    """age -> report group label, 10-year bins with '80+' on top (calc/simulation.py:103-116)."""
+    out = []
+    for i in range(0, max_age + 1):
+        grp = i // 10
+        out.append('80+' if grp >= 8 else '%d–%d' % (grp * 10, grp * 10 + 9))
+    return out

@@ -163,6 +163,25 @@ def gen_inputs():
         json.dump(inputs, f)
     print('inputs.json: N=%d, %d contact rows' % (ages.sum(), len(rows)))
 
+    # Package input data (reina_model_amd/data/): the FI rows of data/contact_matrix.csv in their
+    # wide form + the HUS age histogram. Data only; `reina_model_amd.datasets` re-expands it.
+    # values are taken from the DataFrame the reference itself parsed (pandas' C float parser is
+    # not round-trip exact, so re-parsing the CSV text with float() would differ in the last ulp)
+    wdf = rh.setup()['datasets'].get_contacts_for_country()
+    ccols = [c for c in wdf.columns if c not in ('place_type', 'participant_age')]
+    cgroups = [[int(y) for y in c.split('-')] for c in ccols]
+    wide = []
+    for _, t in wdf.iterrows():
+        lo, hi = [int(y) for y in t['participant_age'].split('-')]
+        wide.append([t['place_type'], lo, hi, [float(t[c]) for c in ccols]])
+    pkg = dict(country=v['country'], area_name=v['area_name'], contact_groups=cgroups,
+               contact_rows=wide, age_counts=[int(x) for x in ages.values])
+    pkg_dir = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'reina_model_amd', 'data')
+    os.makedirs(pkg_dir, exist_ok=True)
+    with open(os.path.join(pkg_dir, 'fi_hus.json'), 'w') as f:
+        json.dump(pkg, f)
+    print('reina_model_amd/data/fi_hus.json: %d wide rows' % len(wide))
+
 
 def gen_rng_kat():
     """G4: known answers at the RandomPool boundary (simrandom.pyx:13-55)."""

@@ -1,0 +1,112 @@
+"""Pins the sequential CPU oracle (oracle/reina_seq.c, "A") against vectors recorded from the REAL
+reference cythonsim in the build container (tests/golden/make_golden.py).  Bit-exact everywhere:
+integer histograms, float scalars (`r`, `mobility_limitation`), RNG doubles.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN, compare_day, load_run, variables_for
+from oracle import seq_oracle as so
+
+
+def _run_and_compare(name, max_days=None):
+    z, meta = load_run(name)
+    ctx = so.make_context(variables_for(meta), meta['age_counts'], meta['seed'],
+                          interventions=meta['interventions'])
+    days = meta['days'] if max_days is None else min(max_days, meta['days'])
+    for d in range(days):
+        compare_day(ctx.generate_state(), z, meta, d)
+        ctx.iterate()
+    if days == meta['days']:
+        for i, w in enumerate(('dead', 'all_infected', 'all_detected')):
+            assert np.array_equal(ctx.get_population_stats(w), z['per_age_final'][i])
+
+
+@pytest.mark.parametrize('name', ['mini_default_s%d' % s for s in range(8)])
+def test_mini_default_scenario_bit_exact(name):
+    """HUS default interventions (testing modes, contact tracing, masks, mobility, imports) on a
+    20k-agent population with binding bed/ICU capacity."""
+    _run_and_compare(name)
+
+
+@pytest.mark.parametrize('name', ['mini_imports_s%d' % s for s in range(4)])
+def test_mini_imports_only_bit_exact(name):
+    """Transmission isolated: imports only, no testing / mobility / masks."""
+    _run_and_compare(name)
+
+
+@pytest.mark.parametrize('name', ['mini_kitchen_s%d' % s for s in range(6)])
+def test_mini_kitchen_sink_bit_exact(name):
+    """Every intervention type incl. vaccination, new beds/ICU, variant imports, weekly variant
+    shares, p_icu_death_no_beds < 1 (ICU accounting drift, quirk Q7)."""
+    _run_and_compare(name)
+
+
+@pytest.mark.slow
+def test_hus_default_seed0_first_150_days_bit_exact():
+    """Full HUS population (1 685 983 agents), default scenario; 150 days covers the first wave,
+    bed/ICU saturation and the start of contact tracing (day 118)."""
+    _run_and_compare('hus_default_s0', max_days=150)
+
+
+def test_hus_age_structure_fixture():
+    from reina_model_amd import datasets
+    _, meta = load_run('hus_default_s0')
+    assert sum(meta['age_counts']) == 1685983
+    assert list(datasets.get_population_for_area()) == meta['age_counts']
+
+
+# ---- RandomPool known answers (simrandom.pyx:13-55) ----
+
+@pytest.fixture(scope='module')
+def kat():
+    return np.load(os.path.join(GOLDEN, 'rng_kat.npz'))
+
+
+@pytest.mark.parametrize('seed', [0, 1, 4321])
+def test_pcg64_double_uint32_and_halfword_buffering(kat, seed):
+    assert np.array_equal(so.rng_pattern(seed, 'd' * 1000), kat['s%d_double' % seed])
+    assert np.array_equal(so.rng_pattern(seed, 'u' * 1001), kat['s%d_uint32' % seed])
+    pat = bytes(kat['mixed_pattern']).decode()
+    assert np.array_equal(so.rng_pattern(seed, pat), kat['s%d_mixed' % seed])
+
+
+@pytest.mark.parametrize('seed', [0, 1, 4321])
+def test_lognormal_and_gamma_known_answers(kat, seed):
+    got = so.rng_pattern(seed, 'l' * 20000, 0.0, 0.5)
+    assert np.array_equal(got, kat['s%d_lognormal_0_0.5' % seed])
+    for mu, cv in ((5.1, 0.86), (21.0, 0.45), (18.8, 0.45)):
+        got = so.rng_pattern(seed, 'g' * 20000, mu, cv)
+        assert np.array_equal(got, kat['s%d_gamma_%g_%g' % (seed, mu, cv)]), (mu, cv)
+    pat = bytes(kat['interleaved_pattern']).decode()
+    got = so.rng_pattern(seed, pat, 5.1, 0.86)
+    assert np.array_equal(got, kat['s%d_interleaved_5.1_0.86' % seed])
+
+
+@pytest.mark.parametrize('seed', [0, 1, 4321])
+def test_legacy_shuffle_is_frozen(kat, seed):
+    assert np.array_equal(so.legacy_shuffled_indices(seed, 1000), kat['s%d_legacy_shuffle_1000' % seed])
+
+
+# ---- Context.sample() (main.pyx:2047-2101) ----
+
+def test_sample_draws_match_reference():
+    z = np.load(os.path.join(GOLDEN, 'samples.npz'))
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    import copy
+    ages = z['age_counts']
+    n = 0
+    for key in z.files:
+        if key == 'age_counts' or key.startswith('chain77'):
+            continue
+        what, age, sev = key.split('|')
+        ctx = so.make_context(copy.deepcopy(VARIABLE_DEFAULTS), ages, 4321, interventions=[])
+        got = ctx.sample(what, int(age), sev or None)
+        assert np.array_equal(got, z[key]), key
+        n += 1
+    assert n == 31
+    ctx = so.make_context(copy.deepcopy(VARIABLE_DEFAULTS), ages, 77, interventions=[])
+    assert np.array_equal(ctx.sample('contacts_per_day', 33), z['chain77|contacts_per_day|33'])
+    assert np.array_equal(ctx.sample('incubation_period', 33), z['chain77|incubation_period|33'])
