@@ -1,0 +1,214 @@
+/* include/reina_hip.h -- C ABI of the MI355X-native REINA agent engine (libreina_hip.so).
+ *
+ * The reference has no C-level plugin interface: its boundary is the Python extension module
+ * `cythonsim.model` (cythonsim/main.pyx, imported at calc/simulation.py:14).  This header is the
+ * FFI a Python `Context` with the reference's method set binds instead of the Cython class
+ * (reina_model_amd/model.py; binding shown in INTEGRATION.md).  Each entry point names the
+ * reference code it replaces.
+ *
+ * Conventions: `extern "C"`, plain structs / pointers / sizes, no torch or C++ types.  Every
+ * function returns 0 on success or a negative REINA_E_* code.  "dev" pointers are device (HBM)
+ * addresses owned by the caller (PyTorch-ROCm tensors); the library never frees them.  All work
+ * is enqueued on the `stream` passed in (a hipStream_t as void*); nothing here synchronises
+ * except reina_read_* which copy to host.
+ */
+#ifndef REINA_HIP_H
+#define REINA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REINA_MAX_AGES 128      /* A: ages 0..A-1 (reference: 101, main.pyx:1355) */
+#define REINA_MAX_VARIANTS 4    /* wild-type + 3 (reference default: 2, variables.py:413-435) */
+#define REINA_MAX_ENTRIES 96    /* contact entries per participant age (reference: 6 places x 15 ranges = 90) */
+#define REINA_NR_PLACES 6       /* main.pyx:64-74 */
+#define REINA_IOT_LEN 21        /* infectiousness profile day -10..10, main.pyx:660-682 */
+#define REINA_MAX_IMPORT_CLASSES 16
+#define REINA_MAX_IMPORT_BATCHES 16
+#define REINA_MAX_VACCINATIONS 16
+#define REINA_MAX_HOSP_EVENTS 16384
+
+/* error codes */
+#define REINA_OK 0
+#define REINA_E_INVALID (-1)
+#define REINA_E_HIP (-2)
+#define REINA_E_NOT_BOUND (-3)
+
+/* problem codes reported by the engine (reina_read_counters scalar REINA_S_PROBLEM); 1..9 are the
+ * reference's SimulationProblem values (main.pyx:51-61), >= 100 are capacity overflows of this
+ * engine's work lists. */
+#define REINA_PROBLEM_WORK_OVERFLOW 100
+#define REINA_PROBLEM_CANDIDATE_OVERFLOW 101
+#define REINA_PROBLEM_QUEUE_OVERFLOW 102
+#define REINA_PROBLEM_HOSPITAL_OVERFLOW 103
+#define REINA_PROBLEM_DAYS_OVERFLOW 104
+
+/* per-age counter arrays, Population stats main.pyx:1335-1341 */
+enum {
+    REINA_C_INFECTED = 0, REINA_C_DETECTED, REINA_C_ALL_DETECTED, REINA_C_ALL_INFECTED,
+    REINA_C_IN_WARD, REINA_C_HOSPITALIZED, REINA_C_IN_ICU, REINA_C_CUM_ICU, REINA_C_DEAD,
+    REINA_C_SUSCEPTIBLE, REINA_C_RECOVERED, REINA_C_VACCINATED, REINA_C_NON_HOSPITAL_DEATHS,
+    REINA_C_NEW_INFECTIONS, REINA_C_NR
+};
+
+/* scalar slots following the per-age arrays (Context / HealthcareSystem scalars,
+ * main.pyx:452-453,1756; daily_contacts :1341; infected_by_variant :1338) */
+enum {
+    REINA_S_AVAILABLE_BEDS = 0, REINA_S_AVAILABLE_ICU, REINA_S_BEDS, REINA_S_ICU_UNITS,
+    REINA_S_TOTAL_INFECTIONS, REINA_S_TOTAL_INFECTORS, REINA_S_EXPOSED_PER_DAY,
+    REINA_S_CT_CASES_PER_DAY, REINA_S_PROBLEM, REINA_S_DAY, REINA_S_UNABLE_TO_IMPORT,
+    REINA_S_QUEUE_LEN,
+    REINA_S_DAILY_CONTACTS = 16,                        /* [6] */
+    REINA_S_INFECTED_BY_VARIANT = 24,                   /* [4] */
+    REINA_S_NR = 32
+};
+#define REINA_COUNTER_WORDS (REINA_C_NR * REINA_MAX_AGES + REINA_S_NR)
+
+/* control block (device, int32): list lengths and cursors the kernels hand to each other */
+enum {
+    REINA_L_WORK = 0, REINA_L_CAND, REINA_L_QUEUE0, REINA_L_QUEUE1, REINA_L_LEVEL1, REINA_L_HOSP,
+    REINA_L_CONTACTS, REINA_L_HOSP_ADMIT, REINA_L_ICU_ADMIT,
+    REINA_L_VACC_CURSOR = 16,                           /* [REINA_MAX_VACCINATIONS] */
+    REINA_L_NR = 32
+};
+
+typedef struct {
+    uint32_t n_agents;        /* agents of this engine instance, sorted by age */
+    uint32_t nr_ages;         /* A */
+    uint32_t nr_variants;     /* V */
+    uint32_t reserved0;
+    uint64_t seed;            /* Philox key (random_seed of Context, main.pyx:1759) */
+    uint32_t max_work_items;  /* capacity of work_items (records) */
+    uint32_t max_candidates;  /* capacity of candidates (records) */
+    uint32_t max_queue;       /* capacity of each testing queue */
+    uint32_t reserved1;
+    int32_t age_start[REINA_MAX_AGES + 1]; /* first agent index of each age; [A] = n_agents
+                                              (Population.age_start, main.pyx:1332,1442) */
+} reina_config_t;
+
+/* Disease parameters, all float32 like the reference's `cdef float` fields (main.pyx:787-806).
+ * Age-classed step functions (ClassifiedValues + cv_get_greatest_lte, main.pyx:684-730) are
+ * expanded per age by the host. Conditional probabilities as produced by variant_init :834-843. */
+typedef struct {
+    float infectiousness_multiplier[REINA_MAX_VARIANTS];
+    float p_asymptomatic_infection[REINA_MAX_VARIANTS];
+    float p_hospital_death_no_beds[REINA_MAX_VARIANTS];
+    float p_icu_death_no_beds[REINA_MAX_VARIANTS];
+    float mean_incubation_duration[REINA_MAX_VARIANTS];
+    float mean_duration_from_onset_to_death[REINA_MAX_VARIANTS];
+    float mean_duration_from_onset_to_recovery[REINA_MAX_VARIANTS];
+    float ratio_of_duration_before_hospitalisation[REINA_MAX_VARIANTS];
+    float ratio_of_duration_in_ward[REINA_MAX_VARIANTS];
+    float p_mask_protects_others[REINA_MAX_VARIANTS];
+    float p_mask_protects_wearer[REINA_MAX_VARIANTS];
+    float infectiousness_over_time[REINA_MAX_VARIANTS][REINA_IOT_LEN + 3]; /* day -10..10 */
+    float p_susceptibility[REINA_MAX_VARIANTS][REINA_MAX_AGES];
+    /* severity is always drawn with the target's pre-infection variant, i.e. 0 (quirk Q3,
+     * main.pyx:211-212 vs :224-225) */
+    float p_symptomatic[REINA_MAX_AGES];
+    float p_severe_given_symptomatic[REINA_MAX_AGES];
+    float p_critical_given_severe[REINA_MAX_AGES];
+    float p_fatal_given_critical[REINA_MAX_AGES];
+    float p_death_outside_hospital[REINA_MAX_AGES];
+    /* imported infection age classes (main.pyx:1376-1384,1632-1650) */
+    uint32_t n_import_classes;
+    int32_t import_class_min_age[REINA_MAX_IMPORT_CLASSES];
+    int32_t import_class_max_age[REINA_MAX_IMPORT_CLASSES];
+    float import_class_cum[REINA_MAX_IMPORT_CLASSES];
+} reina_disease_t;
+
+/* Contact sampling tables for one rebuild (ContactMatrix.generate_contact_probabilities,
+ * main.pyx:1184-1235), host arrays:
+ *   nr_contacts_by_age[A]          float32(total contacts/day)
+ *   count[A]                       entries per age (<= REINA_MAX_ENTRIES)
+ *   threshold[A][REINA_MAX_ENTRIES] uint32 floor(cum_p * 2^32) (saturated), padded with 0xFFFFFFFF
+ *   meta[A][REINA_MAX_ENTRIES]      place | cmin << 8 | cmax << 16
+ *   mask_p[A][8]                    float32 mask probability by (participant age, place) */
+typedef struct {
+    const float *nr_contacts_by_age;
+    const int32_t *count;
+    const uint32_t *threshold;
+    const uint32_t *meta;
+    const float *mask_p;
+} reina_contact_tables_t;
+
+/* Per-agent state and work lists: device pointers owned by the caller. */
+typedef struct {
+    uint32_t *hot;            /* [N] packed hot word, layout in reina_prims.h */
+    int32_t *infector;        /* [N] Person.infector, -1 = none */
+    int32_t *n_infected;      /* [N] Person.other_people_infected */
+    float *onset_days;        /* [N] Person.days_from_onset_to_removed */
+    int32_t *vacc_day;        /* [N] Person.day_of_vaccination, -1 = never */
+    int32_t *first_infectee;  /* [N] head of the infectee list (Person.infectees), -1 = empty */
+    int32_t *next_sibling;    /* [N] next infectee of the same infector, -1 = end */
+    uint64_t *claim;          /* [N] winner-selection keys, init 0xFF..FF */
+    int32_t *counters;        /* [REINA_COUNTER_WORDS] */
+    int32_t *control;         /* [REINA_L_NR] */
+    uint32_t *work_items;     /* [max_work_items * 4] (src, nr | variant << 8 | age << 16, src_inf bits, pad) */
+    uint32_t *candidates;     /* [max_candidates * 4] (target, src, variant, prio) */
+    uint32_t *queue0;         /* [max_queue] testing queue, even days */
+    uint32_t *queue1;         /* [max_queue] testing queue, odd days */
+    uint32_t *level1;         /* [max_queue] contact-tracing level-1 work list */
+    uint64_t *hosp_events;    /* [REINA_MAX_HOSP_EVENTS] */
+} reina_buffers_t;
+
+/* `pre_init` = 1 for batches that come from an `import-infections` intervention: the reference
+ * applies those BEFORE Population.init_day zeroes new_infections / infected_by_variant
+ * (main.pyx:2013-2016 then :1687-1699), so they do not show up in those daily counters; weekly
+ * imports (infect_people_daily, :1671-1685) run after the zeroing and do. */
+typedef struct { uint32_t count; uint32_t variant; uint32_t pre_init; uint32_t reserved; } reina_import_batch_t;
+/* vaccinate `nr` agents per day among sorted indices [idx_start, idx_end), oldest first
+ * (HealthcareSystem.vaccinate_people main.pyx:560-583); `slot` keeps the device-side cursor */
+typedef struct { uint32_t nr; uint32_t idx_start; uint32_t idx_end; uint32_t slot; } reina_vaccination_t;
+
+/* Everything the host decides for one day (Context.iterate main.pyx:2011-2016 +
+ * apply_intervention :1880-1960 + infect_people_daily :1671-1685). */
+typedef struct {
+    uint32_t day;
+    uint32_t testing_mode;            /* TestingMode main.pyx:441-445 */
+    float p_detected_anyway;
+    float p_successful_tracing;
+    int32_t add_beds;                 /* build-new-hospital-beds */
+    int32_t add_icu_units;            /* build-new-icu-units */
+    uint32_t n_import_batches;
+    uint32_t n_vaccinations;
+    reina_import_batch_t import_batches[REINA_MAX_IMPORT_BATCHES];
+    reina_vaccination_t vaccinations[REINA_MAX_VACCINATIONS];
+    int32_t *history_row;             /* dev, optional: counters are copied here BEFORE the day runs
+                                         (= generate_state() taken before iterate(), simulation.py:195) */
+} reina_day_t;
+
+typedef struct reina_engine reina_engine_t;
+
+/* replaces Context.__init__ / Population.__init__ / Disease.__init__ (main.pyx:1759-1781,
+ * 1354-1450, 868-881) */
+int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, reina_engine_t **out);
+int reina_destroy(reina_engine_t *e);
+/* attach caller-owned state; reina_init_state fills it like _create_agents/_init_stats
+ * (main.pyx:1389-1450): all susceptible, counters = age histogram, beds/ICU free */
+int reina_bind_buffers(reina_engine_t *e, const reina_buffers_t *buffers);
+int reina_init_state(reina_engine_t *e, int32_t hospital_beds, int32_t icu_units, void *stream);
+/* replaces ContactMatrix.generate_contact_probabilities upload (main.pyx:1184-1235) */
+int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t *t, void *stream);
+/* replaces Context.iterate() for one day (main.pyx:2011-2018) */
+int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream);
+/* runs `n_days` consecutive days from an array of day descriptors (the loop of
+ * calc/simulation.py:194-270 without the per-day host round trip) */
+int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, void *stream);
+/* replaces Context.generate_state's reads (main.pyx:1813-1857): copies the counter block to host
+ * (synchronises `stream`) */
+int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);
+/* timing hooks for bench.py: HIP events recorded around the scan kernel on `stream` */
+int reina_profile_enable(reina_engine_t *e, int enable);
+int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_launches,
+                       double *all_ms_total);
+const char *reina_last_error(void);
+int reina_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REINA_HIP_H */

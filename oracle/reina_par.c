@@ -1,0 +1,733 @@
+/* oracle/reina_par.c -- TEST INFRASTRUCTURE (oracle "B"), never linked into the product.
+ *
+ * Plain-C, single-threaded restatement of the PARALLEL formulation of the reference's day step
+ * (SURVEY.md Appendix B): the same model as cythonsim/main.pyx, reorganised into order-free
+ * phases (imports -> test queue/tracing/vaccination -> scan -> hospital -> contacts -> install)
+ * with every random decision keyed by (agent, day, purpose) on Philox instead of the reference's
+ * sequential PCG64 stream.  The HIP engine must reproduce this program's integer state
+ * BIT-EXACTLY (tests/test_parity_gpu.py); this program is tied to the reference statistically
+ * (ensemble tolerance vs the bit-exact sequential oracle A, tests/test_par_vs_seq.py) because a
+ * parallel engine cannot replay the PCG64 stream order.
+ *
+ * Written independently of the kernels (simple loops, arrays, qsort); it shares only the numeric
+ * primitives header (Philox, reproducible exp/log/normal/gamma, hot-word bit layout) and the ABI
+ * structs.  Exposes the engine ABI of include/reina_hip.h with a `par_` prefix and host memory.
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/reina_hip.h"
+#include "../reina_model_amd/csrc/reina_prims.h"
+
+typedef struct {
+    reina_config_t cfg;
+    reina_disease_t dis;
+    reina_buffers_t buf;
+    int bound;
+    uint32_t k0, k1;
+    /* contact tables (copied) */
+    float nrc[REINA_MAX_AGES];
+    int32_t tcount[REINA_MAX_AGES];
+    uint32_t thr[REINA_MAX_AGES][REINA_MAX_ENTRIES];
+    uint32_t meta[REINA_MAX_AGES][REINA_MAX_ENTRIES];
+    float mask_p[REINA_MAX_AGES][8];
+} Par;
+
+#define CNT(e, c, age) ((e)->buf.counters[(c) * REINA_MAX_AGES + (age)])
+#define SC(e, s) ((e)->buf.counters[REINA_C_NR * REINA_MAX_AGES + (s)])
+#define CTL(e, l) ((e)->buf.control[(l)])
+
+enum { EV_HOSPITALIZE = 0, EV_TO_ICU = 1, EV_RELEASE_WARD = 2, EV_RELEASE_ICU = 3 };
+
+static void set_problem(Par *e, int p) {
+    if (SC(e, REINA_S_PROBLEM) == 0) SC(e, REINA_S_PROBLEM) = p;
+}
+
+/* age of sorted agent index i (Population.age_start, main.pyx:1442) */
+static int age_of(const Par *e, uint32_t i) {
+    int lo = 0, hi = (int)e->cfg.nr_ages - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if ((uint32_t)e->cfg.age_start[mid] <= i)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+int par_abi_version(void) { return 1; }
+
+int par_create(const reina_config_t *cfg, const reina_disease_t *disease, Par **out) {
+    if (cfg->nr_ages > REINA_MAX_AGES || cfg->nr_variants > REINA_MAX_VARIANTS) return REINA_E_INVALID;
+    Par *e = (Par *)calloc(1, sizeof(Par));
+    e->cfg = *cfg;
+    e->dis = *disease;
+    e->k0 = (uint32_t)cfg->seed;
+    e->k1 = (uint32_t)(cfg->seed >> 32);
+    *out = e;
+    return 0;
+}
+int par_destroy(Par *e) {
+    free(e);
+    return 0;
+}
+int par_bind_buffers(Par *e, const reina_buffers_t *b) {
+    e->buf = *b;
+    e->bound = 1;
+    return 0;
+}
+
+/* _create_agents / _init_stats (main.pyx:1389-1450): everyone susceptible */
+int par_init_state(Par *e, int32_t beds, int32_t icu, void *stream) {
+    (void)stream;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    uint32_t N = e->cfg.n_agents;
+    for (uint32_t i = 0; i < N; i++) {
+        e->buf.hot[i] = 0;
+        e->buf.infector[i] = -1;
+        e->buf.n_infected[i] = 0;
+        e->buf.onset_days[i] = 0.0f;
+        e->buf.vacc_day[i] = -1;
+        e->buf.first_infectee[i] = -1;
+        e->buf.next_sibling[i] = -1;
+        e->buf.claim[i] = ~0ull;
+    }
+    memset(e->buf.counters, 0, sizeof(int32_t) * REINA_COUNTER_WORDS);
+    memset(e->buf.control, 0, sizeof(int32_t) * REINA_L_NR);
+    for (uint32_t a = 0; a < e->cfg.nr_ages; a++)
+        CNT(e, REINA_C_SUSCEPTIBLE, a) = e->cfg.age_start[a + 1] - e->cfg.age_start[a];
+    SC(e, REINA_S_AVAILABLE_BEDS) = SC(e, REINA_S_BEDS) = beds;
+    SC(e, REINA_S_AVAILABLE_ICU) = SC(e, REINA_S_ICU_UNITS) = icu;
+    for (int k = 0; k < REINA_MAX_VACCINATIONS; k++) CTL(e, REINA_L_VACC_CURSOR + k) = INT_MIN;
+    return 0;
+}
+
+int par_upload_contact_tables(Par *e, const reina_contact_tables_t *t, void *stream) {
+    (void)stream;
+    uint32_t A = e->cfg.nr_ages;
+    memcpy(e->nrc, t->nr_contacts_by_age, sizeof(float) * A);
+    memcpy(e->tcount, t->count, sizeof(int32_t) * A);
+    memcpy(e->thr, t->threshold, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
+    memcpy(e->meta, t->meta, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
+    memcpy(e->mask_p, t->mask_p, sizeof(float) * A * 8);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- disease helpers */
+
+/* Disease.get_symptom_severity (main.pyx:1042-1091), float32, variant 0 tables (quirk Q3);
+ * both FATAL branches set DEATH_OUTSIDE_HOSPITAL (quirk Q2) */
+static int severity_of(const Par *e, int age, float val, float vmod, int *pod_outside) {
+    const reina_disease_t *d = &e->dis;
+    float syc = d->p_symptomatic[age];
+    *pod_outside = 0;
+    if (val >= syc) return RV_ASYMPTOMATIC;
+    syc *= vmod;
+    float dohc = d->p_death_outside_hospital[age];
+    if (dohc != 0.0f) {
+        if (val < dohc * syc) {
+            *pod_outside = 1;
+            return RV_FATAL;
+        }
+        val = (val - dohc) / (1.0f - dohc);
+    }
+    float sc = d->p_severe_given_symptomatic[age];
+    float cc = d->p_critical_given_severe[age];
+    float fc = d->p_fatal_given_critical[age];
+    if (val < fc * cc * sc * syc) {
+        *pod_outside = 1;
+        return RV_FATAL;
+    }
+    if (val < cc * sc * syc) return RV_CRITICAL;
+    if (val < sc * syc) return RV_SEVERE;
+    return RV_MILD;
+}
+
+static uint32_t clamp_days(Par *e, int d) {
+    if (d < 0) d = 0;
+    if (d > 255) {
+        set_problem(e, REINA_PROBLEM_DAYS_OVERFLOW);
+        d = 255;
+    }
+    return (uint32_t)d;
+}
+
+/* person_infect (main.pyx:209-235) + Population.infect (:1576-1582) */
+static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant, int32_t src,
+                              int fresh, uint32_t testing_mode) {
+    int age = age_of(e, t);
+    uint32_t w = e->buf.hot[t];
+    rp_u4 r = rp_philox(e->k0, e->k1, t, day, RP_P_INFECT, 0);
+    float val = rp_uniform24(r.v[0]);
+    float vmod = 1.0f;
+    if ((w & RH_VACCINATED) && ((int)day - e->buf.vacc_day[t] > 14)) vmod = 0.1f;
+    int pod = 0;
+    int sev = severity_of(e, age, val, vmod, &pod);
+    float g = rp_gamma_mu_cv(e->dis.mean_incubation_duration[0], 0.86f, e->k0, e->k1, t, day, RP_P_INFECT, 1);
+    uint32_t dl = clamp_days(e, rp_round_to_int(g));
+    uint32_t nw = RS_INCUBATION | ((uint32_t)sev << 3) | (variant << 8) | (pod ? RH_POD_OUTSIDE : 0) |
+                  (fresh ? RH_FRESH : 0) | (w & RH_VACCINATED) |
+                  (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0) | (dl << 16);
+    e->buf.hot[t] = nw;
+    if (src >= 0) {
+        e->buf.infector[t] = src;
+        int old = e->buf.n_infected[src]++;
+        if (e->buf.hot[src] & RH_HASLIST) {
+            if (old >= 64) {
+                set_problem(e, 1 /* TOO_MANY_INFECTEES */);
+            } else {
+                e->buf.next_sibling[t] = e->buf.first_infectee[src];
+                e->buf.first_infectee[src] = (int32_t)t;
+            }
+        }
+    }
+    CNT(e, REINA_C_SUSCEPTIBLE, age) -= 1;
+    CNT(e, REINA_C_INFECTED, age) += 1;
+    CNT(e, REINA_C_ALL_INFECTED, age) += 1;
+    CNT(e, REINA_C_NEW_INFECTIONS, age) += 1;
+    SC(e, REINA_S_INFECTED_BY_VARIANT + variant) += 1;
+}
+
+/* person_recover / person_die / person_become_removed (main.pyx:301-318,370-374) */
+static uint32_t do_recover(Par *e, uint32_t w, int age) {
+    CNT(e, REINA_C_INFECTED, age) -= 1;
+    CNT(e, REINA_C_RECOVERED, age) += 1;
+    return RH_SET_STATE(w, RS_RECOVERED) & ~RH_HASLIST;
+}
+static uint32_t do_die(Par *e, uint32_t w, int age) {
+    CNT(e, REINA_C_INFECTED, age) -= 1;
+    CNT(e, REINA_C_DEAD, age) += 1;
+    if (w & RH_POD_OUTSIDE) CNT(e, REINA_C_NON_HOSPITAL_DEATHS, age) += 1;
+    return RH_SET_STATE(w, RS_DEAD) & ~RH_HASLIST;
+}
+
+static void queue_append(Par *e, int which, uint32_t idx) {
+    int l = which ? REINA_L_QUEUE1 : REINA_L_QUEUE0;
+    uint32_t *q = which ? e->buf.queue1 : e->buf.queue0;
+    if ((uint32_t)CTL(e, l) >= e->cfg.max_queue) {
+        set_problem(e, REINA_PROBLEM_QUEUE_OVERFLOW);
+        return;
+    }
+    q[CTL(e, l)++] = idx;
+}
+
+static void level1_append(Par *e, uint32_t idx) {
+    if ((uint32_t)CTL(e, REINA_L_LEVEL1) >= e->cfg.max_queue) {
+        set_problem(e, REINA_PROBLEM_QUEUE_OVERFLOW);
+        return;
+    }
+    e->buf.level1[CTL(e, REINA_L_LEVEL1)++] = idx;
+}
+
+/* ---------------------------------------------------------------- imports (rounds) */
+/* Population.infect_people / get_import_infection_person (main.pyx:1632-1665), parallel form:
+ * 10 rounds; in a round every unplaced import proposes one target; a susceptible target goes to
+ * the lowest import number proposing it; the rest try again next round. */
+static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *import_base) {
+    uint32_t total = 0;
+    for (uint32_t b = 0; b < dp->n_import_batches; b++)
+        if ((int)dp->import_batches[b].pre_init == pre_init) total += dp->import_batches[b].count;
+    if (!total) return;
+    uint32_t *variant = (uint32_t *)malloc(sizeof(uint32_t) * total);
+    uint32_t *target = (uint32_t *)malloc(sizeof(uint32_t) * total);
+    uint8_t *placed = (uint8_t *)calloc(total, 1);
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < dp->n_import_batches; b++)
+        if ((int)dp->import_batches[b].pre_init == pre_init)
+            for (uint32_t k = 0; k < dp->import_batches[b].count; k++) variant[n++] = dp->import_batches[b].variant;
+    const reina_disease_t *d = &e->dis;
+    for (uint32_t round = 0; round < 10; round++) {
+        /* propose */
+        for (uint32_t j = 0; j < total; j++) {
+            target[j] = 0xFFFFFFFFu;
+            if (placed[j]) continue;
+            rp_u4 r = rp_philox(e->k0, e->k1, *import_base + j, dp->day, RP_P_IMPORT, round);
+            float p = rp_uniform24(r.v[0]);
+            uint32_t c = d->n_import_classes - 1;
+            for (uint32_t k = 0; k < d->n_import_classes; k++)
+                if (p <= d->import_class_cum[k]) {
+                    c = k;
+                    break;
+                }
+            uint32_t start = (uint32_t)e->cfg.age_start[d->import_class_min_age[c]];
+            uint32_t end = (uint32_t)e->cfg.age_start[d->import_class_max_age[c] + 1];
+            if (end <= start) continue;
+            uint32_t t = start + r.v[1] % (end - start);
+            if (RH_STATE(e->buf.hot[t]) == RS_SUSCEPTIBLE) target[j] = t;
+        }
+        /* grant: lowest import number per target (claim keys carry the import number) */
+        for (uint32_t j = 0; j < total; j++) {
+            if (target[j] == 0xFFFFFFFFu) continue;
+            uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
+            if (key < e->buf.claim[target[j]]) e->buf.claim[target[j]] = key;
+        }
+        for (uint32_t j = 0; j < total; j++) {
+            if (target[j] == 0xFFFFFFFFu) continue;
+            uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
+            if (e->buf.claim[target[j]] == key) {
+                install_infection(e, target[j], dp->day, variant[j], -1, 1, dp->testing_mode);
+                placed[j] = 1;
+            }
+        }
+    }
+    for (uint32_t j = 0; j < total; j++)
+        if (!placed[j]) SC(e, REINA_S_UNABLE_TO_IMPORT) += 1;
+    *import_base += total;
+    free(variant);
+    free(target);
+    free(placed);
+}
+
+/* ---------------------------------------------------------------- testing queue + tracing */
+/* HealthcareSystem.queue_for_testing via contact tracing (main.pyx:474-488); the success roll is
+ * keyed by (candidate, tracer) so that the SET of queued agents is order-free */
+static int try_queue(Par *e, uint32_t cand, uint32_t tracer, const reina_day_t *dp) {
+    uint32_t w = e->buf.hot[cand];
+    if (RH_STATE(w) == RS_DEAD || (w & (RH_DETECTED | RH_QUEUED))) return 0;
+    rp_u4 r = rp_philox(e->k0, e->k1, cand, dp->day, RP_P_TRACE, tracer);
+    if (!rp_chance(dp->p_successful_tracing, r.v[0])) return 0;
+    e->buf.hot[cand] = w | RH_QUEUED;
+    return 1;
+}
+
+/* HealthcareSystem.iterate (main.pyx:514-558) + perform_contact_tracing (:495-512) */
+static void run_testing(Par *e, const reina_day_t *dp) {
+    int cur = dp->day & 1, nxt = cur ^ 1;
+    uint32_t *q = cur ? e->buf.queue1 : e->buf.queue0;
+    int lcur = cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0;
+    int n = CTL(e, lcur);
+    SC(e, REINA_S_CT_CASES_PER_DAY) = n;
+    /* Q1: every queued test is positive (quirk Q8) */
+    for (int k = 0; k < n; k++) {
+        uint32_t i = q[k];
+        uint32_t w = e->buf.hot[i];
+        if (w & RH_DETECTED) set_problem(e, 7 /* WRONG_STATE */);
+        e->buf.hot[i] = (w & ~RH_QUEUED) | RH_DETECTED;
+        int age = age_of(e, i);
+        CNT(e, REINA_C_DETECTED, age) += 1;
+        CNT(e, REINA_C_ALL_DETECTED, age) += 1;
+    }
+    CTL(e, REINA_L_LEVEL1) = 0;
+    if (dp->testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
+        /* Q2: level 0 -- infector and infectees of every detected case */
+        for (int k = 0; k < n; k++) {
+            uint32_t i = q[k];
+            int32_t inf = e->buf.infector[i];
+            if (inf >= 0 && try_queue(e, (uint32_t)inf, i, dp)) {
+                queue_append(e, nxt, (uint32_t)inf);
+                level1_append(e, (uint32_t)inf);
+            }
+            if (e->buf.hot[i] & RH_HASLIST)
+                for (int32_t c = e->buf.first_infectee[i]; c >= 0; c = e->buf.next_sibling[c])
+                    if (try_queue(e, (uint32_t)c, i, dp)) {
+                        queue_append(e, nxt, (uint32_t)c);
+                        level1_append(e, (uint32_t)c);
+                    }
+        }
+        /* Q3: level 1 -- their infector and infectees, no further recursion */
+        int n1 = CTL(e, REINA_L_LEVEL1);
+        for (int k = 0; k < n1; k++) {
+            uint32_t i = e->buf.level1[k];
+            int32_t inf = e->buf.infector[i];
+            if (inf >= 0 && try_queue(e, (uint32_t)inf, i, dp)) queue_append(e, nxt, (uint32_t)inf);
+            if (e->buf.hot[i] & RH_HASLIST)
+                for (int32_t c = e->buf.first_infectee[i]; c >= 0; c = e->buf.next_sibling[c])
+                    if (try_queue(e, (uint32_t)c, i, dp)) queue_append(e, nxt, (uint32_t)c);
+        }
+    }
+    CTL(e, lcur) = 0;
+}
+
+/* HealthcareSystem.vaccinate_people (main.pyx:560-583): oldest first, persistent cursor (agents
+ * skipped once -- dead, detected or already vaccinated -- stay ineligible forever) */
+static void run_vaccinations(Par *e, const reina_day_t *dp) {
+    for (uint32_t k = 0; k < dp->n_vaccinations; k++) {
+        const reina_vaccination_t *v = &dp->vaccinations[k];
+        int32_t c = CTL(e, REINA_L_VACC_CURSOR + v->slot);
+        if (c == INT_MIN) c = (int32_t)v->idx_end - 1;
+        uint32_t nr = v->nr, done = 0;
+        if (nr > v->idx_end - v->idx_start) nr = v->idx_end - v->idx_start;
+        while (done < nr && c >= (int32_t)v->idx_start) {
+            uint32_t i = (uint32_t)c;
+            c--;
+            uint32_t w = e->buf.hot[i];
+            if (RH_STATE(w) == RS_DEAD || (w & (RH_VACCINATED | RH_DETECTED))) continue;
+            e->buf.hot[i] = w | RH_VACCINATED;
+            e->buf.vacc_day[i] = (int32_t)dp->day;
+            CNT(e, REINA_C_VACCINATED, age_of(e, i)) += 1;
+            done++;
+        }
+        CTL(e, REINA_L_VACC_CURSOR + v->slot) = c;
+    }
+}
+
+/* ---------------------------------------------------------------- scan */
+static void emit_event(Par *e, uint32_t i, uint32_t day, int type) {
+    if (CTL(e, REINA_L_HOSP) >= REINA_MAX_HOSP_EVENTS) {
+        set_problem(e, REINA_PROBLEM_HOSPITAL_OVERFLOW);
+        return;
+    }
+    uint64_t prio = rp_priority20(e->k0, e->k1, i, day);
+    e->buf.hosp_events[CTL(e, REINA_L_HOSP)++] = (prio << 34) | ((uint64_t)i << 2) | (uint64_t)type;
+    if (type == EV_HOSPITALIZE) CTL(e, REINA_L_HOSP_ADMIT) += 1;
+    if (type == EV_TO_ICU) CTL(e, REINA_L_ICU_ADMIT) += 1;
+}
+
+/* person_become_ill (main.pyx:284-291) + get_days_from_onset_to_removed / get_illness_days
+ * (:989-1014) + HealthcareSystem.seek_testing (:595-615) */
+static uint32_t become_ill(Par *e, uint32_t i, uint32_t w, const reina_day_t *dp) {
+    int v = RH_VARIANT(w), sev = RH_SEV(w);
+    float mu = sev == RV_FATAL ? e->dis.mean_duration_from_onset_to_death[v]
+                               : e->dis.mean_duration_from_onset_to_recovery[v];
+    float d = rp_gamma_mu_cv(mu, 0.45f, e->k0, e->k1, i, dp->day, RP_P_ONSET, 1);
+    e->buf.onset_days[i] = d;
+    float f = d;
+    if (sev >= RV_SEVERE) f *= e->dis.ratio_of_duration_before_hospitalisation[v];
+    w = RH_SET_STATE(w, RS_ILLNESS);
+    w = RH_SET_DAYS_LEFT(w, clamp_days(e, rp_round_to_int(f)));
+    w = RH_SET_DOI(w, 0);
+    if (sev != RV_ASYMPTOMATIC && !(w & RH_DETECTED)) {
+        int q = 0;
+        if (dp->testing_mode == RT_ALL_WITH_SYMPTOMS || dp->testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
+            q = 1;
+        } else if (dp->testing_mode == RT_ONLY_SEVERE_SYMPTOMS) {
+            if (sev >= RV_SEVERE)
+                q = 1;
+            else
+                q = rp_chance(dp->p_detected_anyway, rp_philox(e->k0, e->k1, i, dp->day, RP_P_ONSET, 0).v[3]);
+        }
+        if (q && !(w & RH_QUEUED)) {
+            w |= RH_QUEUED;
+            queue_append(e, (dp->day & 1) ^ 1, i);
+        }
+    }
+    return w;
+}
+
+/* Context._process_person + person_advance (main.pyx:1968-1979, 395-438) for every agent */
+static void run_scan(Par *e, const reina_day_t *dp) {
+    uint32_t N = e->cfg.n_agents;
+    const reina_disease_t *d = &e->dis;
+    for (uint32_t i = 0; i < N; i++) {
+        uint32_t w = e->buf.hot[i];
+        uint32_t st = RH_STATE(w);
+        if (st == RS_SUSCEPTIBLE) continue;
+        if (st >= RS_RECOVERED) {
+            if (!(w & RH_INCLUDED)) {
+                SC(e, REINA_S_TOTAL_INFECTORS) += 1;
+                SC(e, REINA_S_TOTAL_INFECTIONS) += e->buf.n_infected[i];
+                e->buf.hot[i] = w | RH_INCLUDED;
+            }
+            continue;
+        }
+        if (st == RS_INCUBATION && (w & RH_FRESH)) {
+            e->buf.hot[i] = w & ~RH_FRESH;
+            continue;
+        }
+        int age = age_of(e, i);
+        int v = RH_VARIANT(w), sev = RH_SEV(w);
+        uint32_t dl = RH_DAYS_LEFT(w);
+        if (st == RS_INCUBATION || st == RS_ILLNESS) {
+            /* person_expose_others -> get_exposed_people -> get_contacts (main.pyx:247-281,936-955,
+             * 1308-1320,1539-1573): only the COUNT is drawn here, contacts are realised later */
+            int nr = 0;
+            if (!(w & RH_DETECTED)) {
+                int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w);
+                float inf = (dayrel >= -10 && dayrel <= 10) ? d->infectiousness_over_time[v][dayrel + 10] : 0.0f;
+                if (inf != 0.0f) {
+                    float factor = 1.0f;
+                    int limit = 100;
+                    if (st == RS_ILLNESS && sev != RV_ASYMPTOMATIC) {
+                        factor = 0.5f;
+                        limit = 5;
+                    }
+                    float z = rp_normal_from_u32(rp_philox(e->k0, e->k1, i, dp->day, RP_P_NRCONTACTS, 0).v[0]);
+                    float f = rp_expf(0.5f * z) * e->nrc[age];
+                    f *= factor;
+                    if (f < 1.0f) f = 1.0f;
+                    nr = (int)f - 1;
+                    if (nr > limit) nr = limit;
+                    if (nr > 0) {
+                        float src_inf = inf;
+                        if (sev == RV_ASYMPTOMATIC) src_inf *= d->p_asymptomatic_infection[v];
+                        if ((uint32_t)CTL(e, REINA_L_WORK) >= e->cfg.max_work_items) {
+                            set_problem(e, REINA_PROBLEM_WORK_OVERFLOW);
+                        } else {
+                            uint32_t *wi = e->buf.work_items + 4u * (uint32_t)CTL(e, REINA_L_WORK)++;
+                            wi[0] = i;
+                            wi[1] = (uint32_t)nr | ((uint32_t)v << 8) | ((uint32_t)age << 16);
+                            wi[2] = rp_f2u(src_inf);
+                            wi[3] = 0;
+                        }
+                    }
+                }
+            }
+            SC(e, REINA_S_EXPOSED_PER_DAY) += nr;
+            if (st == RS_INCUBATION) {
+                if (dl > 0) dl--;
+                if (dl == 0)
+                    w = become_ill(e, i, w, dp);
+                else
+                    w = RH_SET_DAYS_LEFT(w, dl);
+            } else {
+                uint32_t doi = RH_DOI(w);
+                if (doi < 255) doi++;
+                if (dl > 0) dl--;
+                w = RH_SET_DOI(RH_SET_DAYS_LEFT(w, dl), doi);
+                if (dl == 0) {
+                    if (sev == RV_FATAL && (w & RH_POD_OUTSIDE))
+                        w = do_die(e, w, age);
+                    else if (sev >= RV_SEVERE)
+                        emit_event(e, i, dp->day, EV_HOSPITALIZE);
+                    else
+                        w = do_recover(e, w, age);
+                }
+            }
+        } else if (st == RS_HOSPITALIZED) {
+            if (dl > 0) dl--;
+            w = RH_SET_DAYS_LEFT(w, dl);
+            if (dl == 0) emit_event(e, i, dp->day, sev >= RV_CRITICAL ? EV_TO_ICU : EV_RELEASE_WARD);
+        } else { /* IN_ICU */
+            if (dl > 0) dl--;
+            w = RH_SET_DAYS_LEFT(w, dl);
+            if (dl == 0) emit_event(e, i, dp->day, EV_RELEASE_ICU);
+        }
+        e->buf.hot[i] = w;
+    }
+}
+
+/* ---------------------------------------------------------------- hospital events */
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* Disease.dies_in_hospital (main.pyx:957-974) */
+static int dies_in_hospital(Par *e, uint32_t i, uint32_t day, int sev, int v, int care) {
+    if (sev == RV_FATAL) return 1;
+    float p = 0.0f;
+    if (sev == RV_CRITICAL) {
+        if (care) return 0;
+        p = e->dis.p_icu_death_no_beds[v];
+    } else if (sev == RV_SEVERE) {
+        if (care) return 0;
+        p = e->dis.p_hospital_death_no_beds[v];
+    }
+    return rp_chance(p, rp_philox(e->k0, e->k1, i, day, RP_P_HOSPITAL, 0).v[0]);
+}
+
+/* person_hospitalize / transfer_to_icu / release_from_hospital (main.pyx:321-367) +
+ * HealthcareSystem bed accounting (:617-651), in priority order when capacity can bind */
+static void run_hospital(Par *e, const reina_day_t *dp) {
+    int M = CTL(e, REINA_L_HOSP);
+    if (!M) return;
+    int b = SC(e, REINA_S_AVAILABLE_BEDS), c = SC(e, REINA_S_AVAILABLE_ICU);
+    if (!(b >= CTL(e, REINA_L_HOSP_ADMIT) && c >= CTL(e, REINA_L_ICU_ADMIT)))
+        qsort(e->buf.hosp_events, (size_t)M, sizeof(uint64_t), cmp_u64);
+    const reina_disease_t *d = &e->dis;
+    for (int k = 0; k < M; k++) {
+        uint64_t ev = e->buf.hosp_events[k];
+        int type = (int)(ev & 3);
+        uint32_t i = (uint32_t)((ev >> 2) & 0xFFFFFFFFu);
+        uint32_t w = e->buf.hot[i];
+        int age = age_of(e, i), v = RH_VARIANT(w), sev = RH_SEV(w);
+        float od = e->buf.onset_days[i];
+        if (type == EV_HOSPITALIZE) {
+            if (!(w & RH_DETECTED)) {
+                w |= RH_DETECTED;
+                CNT(e, REINA_C_DETECTED, age) += 1;
+                CNT(e, REINA_C_ALL_DETECTED, age) += 1;
+            }
+            if (b == 0) {
+                w = dies_in_hospital(e, i, dp->day, sev, v, 0) ? do_die(e, w, age) : do_recover(e, w, age);
+            } else {
+                b--;
+                float f;
+                if (sev == RV_SEVERE)
+                    f = od * (1.0f - d->ratio_of_duration_before_hospitalisation[v]);
+                else
+                    f = od * d->ratio_of_duration_in_ward[v];
+                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)));
+                CNT(e, REINA_C_HOSPITALIZED, age) += 1;
+                CNT(e, REINA_C_IN_WARD, age) += 1;
+            }
+        } else if (type == EV_TO_ICU) {
+            b++;
+            int ok = c > 0;
+            if (ok) c--;
+            if (!ok && dies_in_hospital(e, i, dp->day, sev, v, 0)) {
+                CNT(e, REINA_C_IN_WARD, age) -= 1;
+                CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
+                w = do_die(e, w, age);
+            } else {
+                float f = 1.0f - d->ratio_of_duration_in_ward[v] - d->ratio_of_duration_before_hospitalisation[v];
+                f *= od;
+                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)));
+                CNT(e, REINA_C_IN_WARD, age) -= 1;
+                CNT(e, REINA_C_IN_ICU, age) += 1;
+                CNT(e, REINA_C_CUM_ICU, age) += 1;
+            }
+        } else if (type == EV_RELEASE_WARD) {
+            CNT(e, REINA_C_IN_WARD, age) -= 1;
+            CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
+            b++;
+            w = dies_in_hospital(e, i, dp->day, sev, v, 1) ? do_die(e, w, age) : do_recover(e, w, age);
+        } else {
+            CNT(e, REINA_C_IN_ICU, age) -= 1;
+            CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
+            c++;
+            w = dies_in_hospital(e, i, dp->day, sev, v, 1) ? do_die(e, w, age) : do_recover(e, w, age);
+        }
+        e->buf.hot[i] = w;
+    }
+    SC(e, REINA_S_AVAILABLE_BEDS) = b;
+    SC(e, REINA_S_AVAILABLE_ICU) = c;
+}
+
+/* ---------------------------------------------------------------- contacts + install */
+/* get_one_contact / get_person_from_age_range / person_expose / did_infect
+ * (main.pyx:1290-1304,1525-1535,238-244,908-934) for every sampled contact */
+static void run_contacts(Par *e, const reina_day_t *dp) {
+    const reina_disease_t *d = &e->dis;
+    int W = CTL(e, REINA_L_WORK);
+    for (int k = 0; k < W; k++) {
+        const uint32_t *wi = e->buf.work_items + 4u * (uint32_t)k;
+        uint32_t src = wi[0];
+        int nr = (int)(wi[1] & 0xFF), v = (int)((wi[1] >> 8) & 0xFF), row = (int)(wi[1] >> 16);
+        float src_inf = rp_u2f(wi[2]);
+        uint32_t prio = rp_priority20(e->k0, e->k1, src, dp->day);
+        uint64_t key = rp_order_key(dp->day, prio, src);
+        for (int c = 0; c < nr; c++) {
+            rp_u4 r = rp_philox(e->k0, e->k1, src, dp->day, RP_P_CONTACT, (uint32_t)c);
+            int cnt = e->tcount[row];
+            int ent = cnt - 1;
+            for (int j = 0; j < cnt; j++)
+                if (r.v[0] < e->thr[row][j]) {
+                    ent = j;
+                    break;
+                }
+            uint32_t m = e->meta[row][ent];
+            int place = (int)(m & 0xFF), cmin = (int)((m >> 8) & 0xFF), cmax = (int)((m >> 16) & 0xFF);
+            uint32_t start = (uint32_t)e->cfg.age_start[cmin], end = (uint32_t)e->cfg.age_start[cmax + 1];
+            SC(e, REINA_S_DAILY_CONTACTS + place) += 1;
+            CTL(e, REINA_L_CONTACTS) += 1;
+            if (end <= start) continue;
+            uint32_t t = start + r.v[1] % (end - start);
+            if (RH_STATE(e->buf.hot[t]) != RS_SUSCEPTIBLE) continue;
+            int age_t = age_of(e, t);
+            float p = src_inf * d->p_susceptibility[v][age_t] * d->infectiousness_multiplier[v];
+            if (!rp_chance(p, r.v[2])) continue;
+            float mp = e->mask_p[row][place];
+            if (mp != 0.0f) {
+                float a = mp * d->p_mask_protects_others[v];
+                float b = mp * d->p_mask_protects_wearer[v];
+                float pm = a + b - a * b;
+                if (rp_chance(pm, r.v[3])) continue;
+            }
+            if (key < e->buf.claim[t]) e->buf.claim[t] = key;
+            if ((uint32_t)CTL(e, REINA_L_CAND) >= e->cfg.max_candidates) {
+                set_problem(e, REINA_PROBLEM_CANDIDATE_OVERFLOW);
+                continue;
+            }
+            uint32_t *cd = e->buf.candidates + 4u * (uint32_t)CTL(e, REINA_L_CAND)++;
+            cd[0] = t;
+            cd[1] = src;
+            cd[2] = (uint32_t)v;
+            cd[3] = prio;
+        }
+    }
+}
+
+static void run_install(Par *e, const reina_day_t *dp) {
+    int C = CTL(e, REINA_L_CAND);
+    for (int k = 0; k < C; k++) {
+        const uint32_t *cd = e->buf.candidates + 4u * (uint32_t)k;
+        if (e->buf.claim[cd[0]] != rp_order_key(dp->day, cd[3], cd[1])) continue;
+        if (RH_STATE(e->buf.hot[cd[0]]) != RS_SUSCEPTIBLE) continue; /* duplicate record of the winner */
+        install_infection(e, cd[0], dp->day, cd[2], (int32_t)cd[1], 0, dp->testing_mode);
+    }
+}
+
+/* Context.iterate (main.pyx:2011-2018) in the parallel formulation */
+int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
+    (void)stream;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    if (dp->history_row) memcpy(dp->history_row, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
+    uint32_t import_base = 0;
+    SC(e, REINA_S_BEDS) += dp->add_beds;
+    SC(e, REINA_S_AVAILABLE_BEDS) += dp->add_beds;
+    SC(e, REINA_S_ICU_UNITS) += dp->add_icu_units;
+    SC(e, REINA_S_AVAILABLE_ICU) += dp->add_icu_units;
+    run_imports(e, dp, 1, &import_base);
+    /* Population.init_day (main.pyx:1687-1699) + Context._iterate zeroing (:1998-2000) */
+    for (int i = 0; i < REINA_NR_PLACES; i++) SC(e, REINA_S_DAILY_CONTACTS + i) = 0;
+    for (uint32_t a = 0; a < e->cfg.nr_ages; a++) {
+        CNT(e, REINA_C_NEW_INFECTIONS, a) = 0;
+        CNT(e, REINA_C_DETECTED, a) = 0;
+    }
+    for (int i = 0; i < REINA_MAX_VARIANTS; i++) SC(e, REINA_S_INFECTED_BY_VARIANT + i) = 0;
+    SC(e, REINA_S_TOTAL_INFECTORS) = 0;
+    SC(e, REINA_S_TOTAL_INFECTIONS) = 0;
+    SC(e, REINA_S_EXPOSED_PER_DAY) = 0;
+    CTL(e, REINA_L_WORK) = 0;
+    CTL(e, REINA_L_CAND) = 0;
+    CTL(e, REINA_L_HOSP) = 0;
+    CTL(e, REINA_L_CONTACTS) = 0;
+    CTL(e, REINA_L_HOSP_ADMIT) = 0;
+    CTL(e, REINA_L_ICU_ADMIT) = 0;
+    run_imports(e, dp, 0, &import_base);
+    run_testing(e, dp);
+    run_vaccinations(e, dp);
+    run_scan(e, dp);
+    run_hospital(e, dp);
+    run_contacts(e, dp);
+    run_install(e, dp);
+    SC(e, REINA_S_DAY) = (int32_t)dp->day + 1;
+    SC(e, REINA_S_QUEUE_LEN) = CTL(e, ((dp->day & 1) ^ 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0);
+    return 0;
+}
+
+int par_run_days(Par *e, const reina_day_t *days, uint32_t n, void *stream) {
+    for (uint32_t k = 0; k < n; k++) {
+        int rc = par_step_day(e, &days[k], stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int par_read_counters(Par *e, int32_t *out, void *stream) {
+    (void)stream;
+    memcpy(out, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
+    return 0;
+}
+int par_profile_enable(Par *e, int en) { (void)e; (void)en; return 0; }
+int par_profile_read(Par *e, double *a, uint64_t *b, double *c) { (void)e; *a = 0; *b = 0; *c = 0; return 0; }
+const char *par_last_error(void) { return ""; }
+
+/* ---- primitive test hooks (checked against scipy / known answers in tests/test_prims.py) ---- */
+void par_test_philox(const uint32_t *key, const uint32_t *ctr, uint32_t *out) {
+    rp_u4 r = rp_philox(key[0], key[1], ctr[0], ctr[1], ctr[2], ctr[3]);
+    memcpy(out, r.v, 16);
+}
+void par_test_expf(const float *x, float *y, int n) { for (int i = 0; i < n; i++) y[i] = rp_expf(x[i]); }
+void par_test_logf(const float *x, float *y, int n) { for (int i = 0; i < n; i++) y[i] = rp_logf(x[i]); }
+void par_test_normal(const uint32_t *r, float *y, int n) { for (int i = 0; i < n; i++) y[i] = rp_normal_from_u32(r[i]); }
+void par_test_gamma(float mu, float cv, uint64_t seed, uint32_t day, uint32_t purpose, float *y, int n) {
+    for (int i = 0; i < n; i++)
+        y[i] = rp_gamma_mu_cv(mu, cv, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, day, purpose, 1);
+}
+void par_test_nr_contacts(uint64_t seed, uint32_t day, float nrc, float factor, int limit, int32_t *y, int n) {
+    for (int i = 0; i < n; i++) {
+        float z = rp_normal_from_u32(rp_philox((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, day, RP_P_NRCONTACTS, 0).v[0]);
+        float f = rp_expf(0.5f * z) * nrc;
+        f *= factor;
+        if (f < 1.0f) f = 1.0f;
+        int nr = (int)f - 1;
+        if (nr > limit) nr = limit;
+        y[i] = nr;
+    }
+}

@@ -1,0 +1,1197 @@
+// reina_hip.hip -- MI355X (gfx950 / CDNA4) agent engine behind the C ABI of include/reina_hip.h.
+//
+// One simulated day (the reference's Context.iterate, cythonsim/main.pyx:2011-2018) is a short
+// sequence of kernels over SoA agent state resident in HBM:
+//
+//   k_prologue  1 workgroup   history snapshot, new beds, imports (claim rounds), daily zeroing,
+//                             vaccination cursor scan                      (main.pyx:1652-1699,560-583)
+//   k_test_*    grid          test queue -> detect, contact tracing level 0 / level 1 (:495-558)
+//   k_scan      grid, stream  every agent's 4-byte hot word: R bookkeeping, state machine,
+//                             contact COUNT draw, hospital events, work items  (:1968-1992,395-438)
+//   k_hospital  1 workgroup   bed / ICU admission in priority order           (:321-367,617-651)
+//   k_contacts  grid          one lane per sampled contact: LDS-staged contact tables, target
+//                             gather, Bernoulli transmission, atomicMin winner claim (:1290-1304,
+//                             1525-1573,908-934)
+//   k_install   grid          winners become INCUBATION (severity + incubation draw) (:209-235)
+//
+// The path is HBM-bound integer / RNG work: no MFMA.  Wave64 ballots compact rare events,
+// per-lane Philox keys every decision by (agent, day, purpose) so results do not depend on launch
+// geometry.  Integer results are bit-identical to oracle/reina_par.c by construction (same
+// primitives header, FP contraction off).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/reina_hip.h"
+#include "reina_prims.h"
+
+#define CNT_IDX(c, age) ((c) * REINA_MAX_AGES + (age))
+#define SC_IDX(s) (REINA_C_NR * REINA_MAX_AGES + (s))
+
+enum { EV_HOSPITALIZE = 0, EV_TO_ICU = 1, EV_RELEASE_WARD = 2, EV_RELEASE_ICU = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// device-side parameter block (one per engine, lives in HBM, read through the scalar/L1 caches)
+struct DevParams {
+    reina_disease_t dis;
+    int32_t age_start[REINA_MAX_AGES + 1];
+    uint32_t n_agents, nr_ages, nr_variants;
+    uint32_t k0, k1;
+    uint32_t max_work_items, max_candidates, max_queue;
+    // contact tables
+    float nrc[REINA_MAX_AGES];
+    int32_t tcount[REINA_MAX_AGES];
+    float mask_p[REINA_MAX_AGES][8];
+};
+
+struct Tables {  // bigger tables staged into LDS by k_contacts
+    uint32_t thr[REINA_MAX_AGES][REINA_MAX_ENTRIES];
+    uint32_t meta[REINA_MAX_AGES][REINA_MAX_ENTRIES];
+};
+
+static thread_local std::string g_last_error;
+
+struct reina_engine {
+    reina_config_t cfg;
+    reina_buffers_t buf;
+    bool bound = false;
+    DevParams *d_params = nullptr;
+    Tables *d_tables = nullptr;
+    DevParams h_params;
+    Tables h_tables;
+    bool testing_ever = false;
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, size_t>> scan_pairs, day_pairs;
+    double scan_ms = 0, all_ms = 0;
+    uint64_t scan_launches = 0;
+};
+
+#define HIP_CHECK(x)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (x);                                                                 \
+        if (_e != hipSuccess) {                                                              \
+            g_last_error = std::string(#x) + ": " + hipGetErrorString(_e);                   \
+            return REINA_E_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+
+// One slot per calling lane from a global counter, one atomic per wave (ballot + popcount).
+__device__ __forceinline__ uint32_t wave_alloc(int32_t *ctr) {
+    uint64_t m = __ballot(1);
+    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+    uint32_t base = 0;
+    if (rank == 0) base = (uint32_t)atomicAdd(ctr, (int)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    return base + rank;
+}
+
+__device__ __forceinline__ void set_problem(int32_t *counters, int p) {
+    atomicCAS(&counters[SC_IDX(REINA_S_PROBLEM)], 0, p);
+}
+
+// age of sorted agent index i; `as` = age_start (LDS or global), search within [lo, hi]
+__device__ __forceinline__ int age_of(const int32_t *as, uint32_t i, int lo, int hi) {
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if ((uint32_t)as[mid] <= i)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t ld_hot(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld_claim(const uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Disease.get_symptom_severity (main.pyx:1042-1091) in float32; both FATAL branches are
+// DEATH_OUTSIDE_HOSPITAL (quirk Q2); variant-0 tables (quirk Q3)
+__device__ int severity_of(const reina_disease_t &d, int age, float val, float vmod, int *pod_outside) {
+    float syc = d.p_symptomatic[age];
+    *pod_outside = 0;
+    if (val >= syc) return RV_ASYMPTOMATIC;
+    syc *= vmod;
+    float dohc = d.p_death_outside_hospital[age];
+    if (dohc != 0.0f) {
+        if (val < dohc * syc) {
+            *pod_outside = 1;
+            return RV_FATAL;
+        }
+        val = (val - dohc) / (1.0f - dohc);
+    }
+    float sc = d.p_severe_given_symptomatic[age];
+    float cc = d.p_critical_given_severe[age];
+    float fc = d.p_fatal_given_critical[age];
+    if (val < fc * cc * sc * syc) {
+        *pod_outside = 1;
+        return RV_FATAL;
+    }
+    if (val < cc * sc * syc) return RV_CRITICAL;
+    if (val < sc * syc) return RV_SEVERE;
+    return RV_MILD;
+}
+
+__device__ __forceinline__ uint32_t clamp_days(int32_t *counters, int d) {
+    if (d < 0) d = 0;
+    if (d > 255) {
+        set_problem(counters, REINA_PROBLEM_DAYS_OVERFLOW);
+        d = 255;
+    }
+    return (uint32_t)d;
+}
+
+// person_infect (main.pyx:209-235) + Population.infect (:1576-1582).  `expect` is the susceptible
+// word the caller saw; the CAS makes duplicate winner records install once.
+__device__ bool install_infection(const DevParams *P, const reina_buffers_t &B, uint32_t t, uint32_t expect,
+                                  uint32_t day, uint32_t variant, int32_t src, int fresh,
+                                  uint32_t testing_mode) {
+    int age = age_of(P->age_start, t, 0, (int)P->nr_ages - 1);
+    rp_u4 r = rp_philox(P->k0, P->k1, t, day, RP_P_INFECT, 0);
+    float val = rp_uniform24(r.v[0]);
+    float vmod = 1.0f;
+    if ((expect & RH_VACCINATED) && ((int)day - B.vacc_day[t] > 14)) vmod = 0.1f;
+    int pod = 0;
+    int sev = severity_of(P->dis, age, val, vmod, &pod);
+    float g = rp_gamma_mu_cv(P->dis.mean_incubation_duration[0], 0.86f, P->k0, P->k1, t, day, RP_P_INFECT, 1);
+    uint32_t dl = clamp_days(B.counters, rp_round_to_int(g));
+    uint32_t nw = RS_INCUBATION | ((uint32_t)sev << 3) | (variant << 8) | (pod ? RH_POD_OUTSIDE : 0u) |
+                  (fresh ? RH_FRESH : 0u) | (expect & RH_VACCINATED) |
+                  (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0u) | (dl << 16);
+    if (atomicCAS(&B.hot[t], expect, nw) != expect) return false;
+    if (src >= 0) {
+        B.infector[t] = src;
+        int old = atomicAdd(&B.n_infected[src], 1);
+        if (ld_hot(&B.hot[src]) & RH_HASLIST) {
+            if (old >= 64) {
+                set_problem(B.counters, 1 /* TOO_MANY_INFECTEES */);
+            } else {
+                B.next_sibling[t] = atomicExch(&B.first_infectee[src], (int32_t)t);
+            }
+        }
+    }
+    atomicAdd(&B.counters[CNT_IDX(REINA_C_SUSCEPTIBLE, age)], -1);
+    atomicAdd(&B.counters[CNT_IDX(REINA_C_INFECTED, age)], 1);
+    atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_INFECTED, age)], 1);
+    atomicAdd(&B.counters[CNT_IDX(REINA_C_NEW_INFECTIONS, age)], 1);
+    atomicAdd(&B.counters[SC_IDX(REINA_S_INFECTED_BY_VARIANT + variant)], 1);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_init: _create_agents / _init_stats (main.pyx:1389-1450)
+__global__ void k_init(const DevParams *P, reina_buffers_t B, int32_t beds, int32_t icu) {
+    uint32_t N = P->n_agents;
+    uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+        B.hot[i] = 0;
+        B.infector[i] = -1;
+        B.n_infected[i] = 0;
+        B.onset_days[i] = 0.0f;
+        B.vacc_day[i] = -1;
+        B.first_infectee[i] = -1;
+        B.next_sibling[i] = -1;
+        B.claim[i] = ~0ull;
+    }
+    if (blockIdx.x == 0) {
+        for (uint32_t k = threadIdx.x; k < REINA_COUNTER_WORDS; k += blockDim.x) {
+            int32_t v = 0;
+            if (k >= CNT_IDX(REINA_C_SUSCEPTIBLE, 0) && k < CNT_IDX(REINA_C_SUSCEPTIBLE, 0) + P->nr_ages) {
+                uint32_t a = k - CNT_IDX(REINA_C_SUSCEPTIBLE, 0);
+                v = P->age_start[a + 1] - P->age_start[a];
+            }
+            if (k == SC_IDX(REINA_S_AVAILABLE_BEDS) || k == SC_IDX(REINA_S_BEDS)) v = beds;
+            if (k == SC_IDX(REINA_S_AVAILABLE_ICU) || k == SC_IDX(REINA_S_ICU_UNITS)) v = icu;
+            B.counters[k] = v;
+        }
+        for (uint32_t k = threadIdx.x; k < REINA_L_NR; k += blockDim.x)
+            B.control[k] = (k >= REINA_L_VACC_CURSOR && k < REINA_L_VACC_CURSOR + REINA_MAX_VACCINATIONS) ? INT_MIN : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_prologue: single workgroup of 1024 threads.
+#define PRO_THREADS 1024
+#define PRO_MAX_IMPORTS 16384
+
+// Population.infect_people / get_import_infection_person (main.pyx:1632-1665), parallel form:
+// 10 rounds; every unplaced import proposes one target per round; a susceptible target goes to the
+// lowest import number proposing it (atomicMin on the claim word); the rest retry next round.
+__device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, int pre_init,
+                            uint32_t *import_base, uint8_t *placed, uint32_t *s_unplaced) {
+    uint32_t total = 0;
+    for (uint32_t b = 0; b < dp.n_import_batches; b++)
+        if ((int)dp.import_batches[b].pre_init == pre_init) total += dp.import_batches[b].count;
+    if (total == 0) return;
+    if (total > PRO_MAX_IMPORTS) {
+        if (threadIdx.x == 0) set_problem(B.counters, REINA_PROBLEM_WORK_OVERFLOW);
+        total = PRO_MAX_IMPORTS;
+    }
+    for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS) placed[j] = 0;
+    __syncthreads();
+    const reina_disease_t &d = P->dis;
+    for (uint32_t round = 0; round < 10; round++) {
+        // propose + claim
+        for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS) {
+            if (placed[j]) continue;
+            rp_u4 r = rp_philox(P->k0, P->k1, *import_base + j, dp.day, RP_P_IMPORT, round);
+            float p = rp_uniform24(r.v[0]);
+            uint32_t c = d.n_import_classes - 1;
+            for (uint32_t k = 0; k < d.n_import_classes; k++)
+                if (p <= d.import_class_cum[k]) {
+                    c = k;
+                    break;
+                }
+            uint32_t start = (uint32_t)P->age_start[d.import_class_min_age[c]];
+            uint32_t end = (uint32_t)P->age_start[d.import_class_max_age[c] + 1];
+            placed[j] = 2;  // proposing nothing
+            if (end <= start) continue;
+            uint32_t t = start + r.v[1] % (end - start);
+            if (RH_STATE(ld_hot(&B.hot[t])) == RS_SUSCEPTIBLE) {
+                atomicMin((unsigned long long *)&B.claim[t],
+                          (unsigned long long)rp_order_key(dp.day, 0xFFFFFu - round, j));
+                placed[j] = 3;  // proposed
+            }
+        }
+        __syncthreads();
+        // grant + install
+        for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS) {
+            uint8_t st = placed[j];
+            if (st == 1) continue;
+            placed[j] = 0;
+            if (st != 3) continue;
+            rp_u4 r = rp_philox(P->k0, P->k1, *import_base + j, dp.day, RP_P_IMPORT, round);
+            float p = rp_uniform24(r.v[0]);
+            uint32_t c = d.n_import_classes - 1;
+            for (uint32_t k = 0; k < d.n_import_classes; k++)
+                if (p <= d.import_class_cum[k]) {
+                    c = k;
+                    break;
+                }
+            uint32_t start = (uint32_t)P->age_start[d.import_class_min_age[c]];
+            uint32_t end = (uint32_t)P->age_start[d.import_class_max_age[c] + 1];
+            uint32_t t = start + r.v[1] % (end - start);
+            if (ld_claim(&B.claim[t]) == rp_order_key(dp.day, 0xFFFFFu - round, j)) {
+                // variant of import j: walk the batches of this phase
+                uint32_t variant = 0, acc = 0;
+                for (uint32_t b = 0; b < dp.n_import_batches; b++) {
+                    if ((int)dp.import_batches[b].pre_init != pre_init) continue;
+                    acc += dp.import_batches[b].count;
+                    if (j < acc) {
+                        variant = dp.import_batches[b].variant;
+                        break;
+                    }
+                }
+                uint32_t w = ld_hot(&B.hot[t]);
+                install_infection(P, B, t, w, dp.day, variant, -1, 1, dp.testing_mode);
+                placed[j] = 1;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *s_unplaced = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS)
+        if (placed[j] != 1) mine++;
+    if (mine) atomicAdd(s_unplaced, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (*s_unplaced) atomicAdd(&B.counters[SC_IDX(REINA_S_UNABLE_TO_IMPORT)], (int)*s_unplaced);
+        *import_base += total;
+    }
+    __syncthreads();
+}
+
+// HealthcareSystem.vaccinate_people (main.pyx:560-583): oldest first from a persistent cursor.
+__device__ void pro_vaccinate(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp,
+                              uint32_t *s_wave_cnt, int32_t *s_scalar) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t k = 0; k < dp.n_vaccinations; k++) {
+        const reina_vaccination_t v = dp.vaccinations[k];
+        int32_t c = B.control[REINA_L_VACC_CURSOR + v.slot];
+        if (c == INT_MIN) c = (int32_t)v.idx_end - 1;
+        uint32_t nr = v.nr, done = 0;
+        if (nr > v.idx_end - v.idx_start) nr = v.idx_end - v.idx_start;
+        while (done < nr && c >= (int32_t)v.idx_start) {
+            int32_t i = c - tid;
+            bool in_range = i >= (int32_t)v.idx_start;
+            uint32_t w = 0;
+            bool elig = false;
+            if (in_range) {
+                w = ld_hot(&B.hot[i]);
+                elig = !(RH_STATE(w) == RS_DEAD || (w & (RH_VACCINATED | RH_DETECTED)));
+            }
+            uint64_t m = __ballot(elig);
+            uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int wv = 0; wv < PRO_THREADS / 64; wv++) {
+                uint32_t n = s_wave_cnt[wv];
+                if (wv < wave) before += n;
+                total += n;
+            }
+            uint32_t pos = done + before + rank;  // 0-based order among eligible, oldest first
+            if (elig && pos < nr) {
+                atomicOr(&B.hot[i], RH_VACCINATED);
+                B.vacc_day[i] = (int32_t)dp.day;
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_VACCINATED, age_of(P->age_start, (uint32_t)i, 0, (int)P->nr_ages - 1))], 1);
+                if (pos == nr - 1) *s_scalar = i - 1;  // the sequential loop stops right after this one
+            }
+            __syncthreads();
+            if (done + total >= nr) {
+                c = *s_scalar;
+                done = nr;
+            } else {
+                done += total;
+                c -= PRO_THREADS;
+            }
+            __syncthreads();
+        }
+        if (c < (int32_t)v.idx_start - 1) c = (int32_t)v.idx_start - 1;
+        if (tid == 0) B.control[REINA_L_VACC_CURSOR + v.slot] = c;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    __shared__ uint8_t placed[PRO_MAX_IMPORTS];
+    __shared__ uint32_t s_wave_cnt[PRO_THREADS / 64];
+    __shared__ uint32_t s_unplaced;
+    __shared__ int32_t s_scalar;
+    __shared__ uint32_t s_import_base;
+    const int tid = threadIdx.x;
+    // generate_state() is taken BEFORE iterate() (calc/simulation.py:195 vs :270)
+    if (dp.history_row)
+        for (int k = tid; k < REINA_COUNTER_WORDS; k += PRO_THREADS) dp.history_row[k] = B.counters[k];
+    if (tid == 0) {
+        s_import_base = 0;
+        B.counters[SC_IDX(REINA_S_BEDS)] += dp.add_beds;
+        B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] += dp.add_beds;
+        B.counters[SC_IDX(REINA_S_ICU_UNITS)] += dp.add_icu_units;
+        B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] += dp.add_icu_units;
+    }
+    __syncthreads();
+    pro_imports(P, B, dp, 1, &s_import_base, placed, &s_unplaced);
+    // Population.init_day (main.pyx:1687-1699) + Context._iterate zeroing (:1998-2000)
+    __threadfence();
+    __syncthreads();
+    for (int k = tid; k < (int)P->nr_ages; k += PRO_THREADS) {
+        B.counters[CNT_IDX(REINA_C_NEW_INFECTIONS, k)] = 0;
+        B.counters[CNT_IDX(REINA_C_DETECTED, k)] = 0;
+    }
+    if (tid < REINA_NR_PLACES) B.counters[SC_IDX(REINA_S_DAILY_CONTACTS + tid)] = 0;
+    if (tid < REINA_MAX_VARIANTS) B.counters[SC_IDX(REINA_S_INFECTED_BY_VARIANT + tid)] = 0;
+    if (tid == 0) {
+        B.counters[SC_IDX(REINA_S_TOTAL_INFECTORS)] = 0;
+        B.counters[SC_IDX(REINA_S_TOTAL_INFECTIONS)] = 0;
+        B.counters[SC_IDX(REINA_S_EXPOSED_PER_DAY)] = 0;
+        B.control[REINA_L_WORK] = 0;
+        B.control[REINA_L_CAND] = 0;
+        B.control[REINA_L_HOSP] = 0;
+        B.control[REINA_L_CONTACTS] = 0;
+        B.control[REINA_L_HOSP_ADMIT] = 0;
+        B.control[REINA_L_ICU_ADMIT] = 0;
+        B.control[REINA_L_LEVEL1] = 0;
+        // HealthcareSystem.iterate: ct_cases_per_day = len(queue) (main.pyx:518-519)
+        B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] = B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
+    }
+    __threadfence();
+    __syncthreads();
+    pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced);
+    // note: vaccination follows the test-queue pass in the reference (main.pyx:547-558); it only
+    // reads DETECTED bits, so it is launched from k_vaccinate after the k_test_* kernels.
+}
+
+__global__ __launch_bounds__(PRO_THREADS) void k_vaccinate(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    __shared__ uint32_t s_wave_cnt[PRO_THREADS / 64];
+    __shared__ int32_t s_scalar;
+    pro_vaccinate(P, B, dp, s_wave_cnt, &s_scalar);
+}
+
+// ---------------------------------------------------------------------------------------------
+// testing queue + contact tracing (HealthcareSystem.iterate main.pyx:514-545,
+// perform_contact_tracing :495-512, queue_for_testing :474-488)
+
+__device__ __forceinline__ void queue_append(const DevParams *P, const reina_buffers_t &B, int which, uint32_t idx) {
+    uint32_t pos = wave_alloc(&B.control[which ? REINA_L_QUEUE1 : REINA_L_QUEUE0]);
+    if (pos >= P->max_queue) {
+        set_problem(B.counters, REINA_PROBLEM_QUEUE_OVERFLOW);
+        return;
+    }
+    (which ? B.queue1 : B.queue0)[pos] = idx;
+}
+
+// Q1: every queued test is positive (quirk Q8): clear QUEUED, set DETECTED
+__global__ void k_test_detect(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    const int cur = dp.day & 1;
+    const uint32_t *q = cur ? B.queue1 : B.queue0;
+    const int n = B.control[cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t i = q[k];
+        uint32_t w = B.hot[i];
+        if (w & RH_DETECTED) set_problem(B.counters, 7 /* WRONG_STATE */);
+        B.hot[i] = (w & ~RH_QUEUED) | RH_DETECTED;
+        int age = age_of(P->age_start, i, 0, (int)P->nr_ages - 1);
+        atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, age)], 1);
+        atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, age)], 1);
+    }
+}
+
+// the tracing success roll is keyed by (candidate, tracer): the SET of queued agents is order-free
+__device__ __forceinline__ bool try_queue(const DevParams *P, const reina_buffers_t &B, uint32_t cand,
+                                          uint32_t tracer, const reina_day_t &dp) {
+    uint32_t w = ld_hot(&B.hot[cand]);
+    if (RH_STATE(w) == RS_DEAD || (w & (RH_DETECTED | RH_QUEUED))) return false;
+    rp_u4 r = rp_philox(P->k0, P->k1, cand, dp.day, RP_P_TRACE, tracer);
+    if (!rp_chance(dp.p_successful_tracing, r.v[0])) return false;
+    uint32_t old = atomicOr(&B.hot[cand], RH_QUEUED);
+    return !(old & RH_QUEUED);
+}
+
+// level 0 (from the detected queue, accepted candidates also go to the level-1 list) and
+// level 1 (from the level-1 list, no further recursion)
+template <int LEVEL>
+__global__ void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    const int cur = dp.day & 1, nxt = cur ^ 1;
+    const uint32_t *src = LEVEL == 0 ? (cur ? B.queue1 : B.queue0) : B.level1;
+    const int n = LEVEL == 0 ? B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] : B.control[REINA_L_LEVEL1];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t i = src[k];
+        int32_t inf = B.infector[i];
+        if (inf >= 0 && try_queue(P, B, (uint32_t)inf, i, dp)) {
+            queue_append(P, B, nxt, (uint32_t)inf);
+            if (LEVEL == 0) {
+                uint32_t pos = wave_alloc(&B.control[REINA_L_LEVEL1]);
+                if (pos < P->max_queue) B.level1[pos] = (uint32_t)inf; else set_problem(B.counters, REINA_PROBLEM_QUEUE_OVERFLOW);
+            }
+        }
+        if (ld_hot(&B.hot[i]) & RH_HASLIST) {
+            for (int32_t c = B.first_infectee[i]; c >= 0; c = B.next_sibling[c]) {
+                if (try_queue(P, B, (uint32_t)c, i, dp)) {
+                    queue_append(P, B, nxt, (uint32_t)c);
+                    if (LEVEL == 0) {
+                        uint32_t pos = wave_alloc(&B.control[REINA_L_LEVEL1]);
+                        if (pos < P->max_queue) B.level1[pos] = (uint32_t)c; else set_problem(B.counters, REINA_PROBLEM_QUEUE_OVERFLOW);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the processed queue is emptied once both tracing levels are done
+__global__ void k_test_finish(reina_buffers_t B, reina_day_t dp) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scan: Context._process_person + person_advance for every agent (main.pyx:1968-1992,395-438)
+#define SCAN_THREADS 256
+enum { SL_INFECTED = 0, SL_RECOVERED, SL_DEAD, SL_NHD, SL_NR };
+
+struct ScanShared {
+    int32_t age_start[REINA_MAX_AGES + 1];
+    int32_t cnt[SL_NR][REINA_MAX_AGES];
+    int32_t total_infectors, total_infections, exposed;
+};
+
+__device__ __forceinline__ void emit_event(const DevParams *P, const reina_buffers_t &B, uint32_t i, uint32_t day, int type) {
+    uint32_t pos = wave_alloc(&B.control[REINA_L_HOSP]);
+    if (pos >= REINA_MAX_HOSP_EVENTS) {
+        set_problem(B.counters, REINA_PROBLEM_HOSPITAL_OVERFLOW);
+        return;
+    }
+    uint64_t prio = rp_priority20(P->k0, P->k1, i, day);
+    B.hosp_events[pos] = (prio << 34) | ((uint64_t)i << 2) | (uint64_t)type;
+    if (type == EV_HOSPITALIZE) atomicAdd(&B.control[REINA_L_HOSP_ADMIT], 1);
+    if (type == EV_TO_ICU) atomicAdd(&B.control[REINA_L_ICU_ADMIT], 1);
+}
+
+// one infected (or newly removed) agent
+__device__ void process_agent(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
+                              uint32_t i, uint32_t w) {
+    const reina_disease_t &d = P->dis;
+    uint32_t st = RH_STATE(w);
+    if (st >= RS_RECOVERED) {
+        // R bookkeeping: the first scan that sees a removed agent (main.pyx:1969-1972)
+        atomicAdd(&S.total_infectors, 1);
+        atomicAdd(&S.total_infections, B.n_infected[i]);
+        B.hot[i] = w | RH_INCLUDED;
+        return;
+    }
+    if (st == RS_INCUBATION && (w & RH_FRESH)) {  // infected earlier today: waits (main.pyx:402)
+        B.hot[i] = w & ~RH_FRESH;
+        return;
+    }
+    int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
+    int v = RH_VARIANT(w), sev = RH_SEV(w);
+    uint32_t dl = RH_DAYS_LEFT(w);
+    if (st == RS_INCUBATION || st == RS_ILLNESS) {
+        // person_expose_others -> get_exposed_people -> get_nr_contacts (main.pyx:247-281,936-955,
+        // 1308-1320): only the COUNT is drawn here; k_contacts realises the contacts
+        int nr = 0;
+        if (!(w & RH_DETECTED)) {
+            int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w);
+            float inf = (dayrel >= -10 && dayrel <= 10) ? d.infectiousness_over_time[v][dayrel + 10] : 0.0f;
+            if (inf != 0.0f) {
+                float factor = 1.0f;
+                int limit = 100;
+                if (st == RS_ILLNESS && sev != RV_ASYMPTOMATIC) {
+                    factor = 0.5f;
+                    limit = 5;
+                }
+                float z = rp_normal_from_u32(rp_philox(P->k0, P->k1, i, dp.day, RP_P_NRCONTACTS, 0).v[0]);
+                float f = rp_expf(0.5f * z) * P->nrc[age];
+                f *= factor;
+                if (f < 1.0f) f = 1.0f;
+                nr = (int)f - 1;
+                if (nr > limit) nr = limit;
+                if (nr > 0) {
+                    float src_inf = inf;
+                    if (sev == RV_ASYMPTOMATIC) src_inf *= d.p_asymptomatic_infection[v];
+                    uint32_t pos = wave_alloc(&B.control[REINA_L_WORK]);
+                    if (pos >= P->max_work_items) {
+                        set_problem(B.counters, REINA_PROBLEM_WORK_OVERFLOW);
+                    } else {
+                        uint4 rec = make_uint4(i, (uint32_t)nr | ((uint32_t)v << 8) | ((uint32_t)age << 16), rp_f2u(src_inf), 0u);
+                        reinterpret_cast<uint4 *>(B.work_items)[pos] = rec;
+                    }
+                }
+            }
+        }
+        if (nr) atomicAdd(&S.exposed, nr);
+        if (st == RS_INCUBATION) {
+            if (dl > 0) dl--;
+            if (dl == 0) {
+                // person_become_ill (main.pyx:284-291, 989-1014) + seek_testing (:595-615)
+                float mu = sev == RV_FATAL ? d.mean_duration_from_onset_to_death[v] : d.mean_duration_from_onset_to_recovery[v];
+                float od = rp_gamma_mu_cv(mu, 0.45f, P->k0, P->k1, i, dp.day, RP_P_ONSET, 1);
+                B.onset_days[i] = od;
+                float f = od;
+                if (sev >= RV_SEVERE) f *= d.ratio_of_duration_before_hospitalisation[v];
+                w = RH_SET_STATE(w, RS_ILLNESS);
+                w = RH_SET_DAYS_LEFT(w, clamp_days(B.counters, rp_round_to_int(f)));
+                w = RH_SET_DOI(w, 0);
+                if (sev != RV_ASYMPTOMATIC && !(w & RH_DETECTED)) {
+                    int q = 0;
+                    if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS || dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
+                        q = 1;
+                    } else if (dp.testing_mode == RT_ONLY_SEVERE_SYMPTOMS) {
+                        if (sev >= RV_SEVERE)
+                            q = 1;
+                        else
+                            q = rp_chance(dp.p_detected_anyway, rp_philox(P->k0, P->k1, i, dp.day, RP_P_ONSET, 0).v[3]);
+                    }
+                    if (q && !(w & RH_QUEUED)) {
+                        w |= RH_QUEUED;
+                        queue_append(P, B, (dp.day & 1) ^ 1, i);
+                    }
+                }
+            } else {
+                w = RH_SET_DAYS_LEFT(w, dl);
+            }
+        } else {
+            uint32_t doi = RH_DOI(w);
+            if (doi < 255) doi++;
+            if (dl > 0) dl--;
+            w = RH_SET_DOI(RH_SET_DAYS_LEFT(w, dl), doi);
+            if (dl == 0) {
+                if (sev == RV_FATAL && (w & RH_POD_OUTSIDE)) {
+                    atomicAdd(&S.cnt[SL_INFECTED][age], -1);
+                    atomicAdd(&S.cnt[SL_DEAD][age], 1);
+                    atomicAdd(&S.cnt[SL_NHD][age], 1);
+                    w = RH_SET_STATE(w, RS_DEAD) & ~RH_HASLIST;
+                } else if (sev >= RV_SEVERE) {
+                    emit_event(P, B, i, dp.day, EV_HOSPITALIZE);
+                } else {
+                    atomicAdd(&S.cnt[SL_INFECTED][age], -1);
+                    atomicAdd(&S.cnt[SL_RECOVERED][age], 1);
+                    w = RH_SET_STATE(w, RS_RECOVERED) & ~RH_HASLIST;
+                }
+            }
+        }
+    } else if (st == RS_HOSPITALIZED) {
+        if (dl > 0) dl--;
+        w = RH_SET_DAYS_LEFT(w, dl);
+        if (dl == 0) emit_event(P, B, i, dp.day, sev >= RV_CRITICAL ? EV_TO_ICU : EV_RELEASE_WARD);
+    } else {
+        if (dl > 0) dl--;
+        w = RH_SET_DAYS_LEFT(w, dl);
+        if (dl == 0) emit_event(P, B, i, dp.day, EV_RELEASE_ICU);
+    }
+    B.hot[i] = w;
+}
+
+__device__ __forceinline__ bool needs_processing(uint32_t w) {
+    uint32_t st = RH_STATE(w);
+    return st != RS_SUSCEPTIBLE && !(st >= RS_RECOVERED && (w & RH_INCLUDED));
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    __shared__ ScanShared S;
+    const int tid = threadIdx.x;
+    for (int k = tid; k <= REINA_MAX_AGES; k += SCAN_THREADS) S.age_start[k] = P->age_start[k];
+    for (int k = tid; k < SL_NR * REINA_MAX_AGES; k += SCAN_THREADS) (&S.cnt[0][0])[k] = 0;
+    if (tid == 0) {
+        S.total_infectors = 0;
+        S.total_infections = 0;
+        S.exposed = 0;
+    }
+    __syncthreads();
+    const uint32_t N = P->n_agents;
+    const uint32_t n4 = N >> 2;
+    const uint4 *hot4 = reinterpret_cast<const uint4 *>(B.hot);
+    const uint32_t stride = gridDim.x * SCAN_THREADS;
+    for (uint32_t q = blockIdx.x * SCAN_THREADS + tid; q < n4; q += stride) {
+        uint4 w4 = hot4[q];
+        if (needs_processing(w4.x)) process_agent(P, B, dp, S, 4 * q + 0, w4.x);
+        if (needs_processing(w4.y)) process_agent(P, B, dp, S, 4 * q + 1, w4.y);
+        if (needs_processing(w4.z)) process_agent(P, B, dp, S, 4 * q + 2, w4.z);
+        if (needs_processing(w4.w)) process_agent(P, B, dp, S, 4 * q + 3, w4.w);
+    }
+    if (blockIdx.x == 0 && tid < (int)(N & 3u)) {
+        uint32_t i = (n4 << 2) + tid;
+        uint32_t w = B.hot[i];
+        if (needs_processing(w)) process_agent(P, B, dp, S, i, w);
+    }
+    __syncthreads();
+    for (int k = tid; k < SL_NR * REINA_MAX_AGES; k += SCAN_THREADS) {
+        int32_t v = (&S.cnt[0][0])[k];
+        if (v) {
+            int c = k / REINA_MAX_AGES, age = k % REINA_MAX_AGES;
+            const int map[SL_NR] = {REINA_C_INFECTED, REINA_C_RECOVERED, REINA_C_DEAD, REINA_C_NON_HOSPITAL_DEATHS};
+            atomicAdd(&B.counters[CNT_IDX(map[c], age)], v);
+        }
+    }
+    if (tid == 0) {
+        if (S.total_infectors) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTORS)], S.total_infectors);
+        if (S.total_infections) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTIONS)], S.total_infections);
+        if (S.exposed) atomicAdd(&B.counters[SC_IDX(REINA_S_EXPOSED_PER_DAY)], S.exposed);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hospital: person_hospitalize / transfer_to_icu / release_from_hospital (main.pyx:321-367) +
+// HealthcareSystem bed accounting (:617-651). One workgroup; when capacity can bind, events are
+// bitonic-sorted by (priority, agent) in LDS and the saturating bed/ICU walk is replayed in order.
+#define HOSP_THREADS 1024
+
+__device__ __forceinline__ int dies_in_hospital(const DevParams *P, uint32_t i, uint32_t day, int sev, int v, int care) {
+    if (sev == RV_FATAL) return 1;
+    float p = 0.0f;
+    if (sev == RV_CRITICAL) {
+        if (care) return 0;
+        p = P->dis.p_icu_death_no_beds[v];
+    } else if (sev == RV_SEVERE) {
+        if (care) return 0;
+        p = P->dis.p_hospital_death_no_beds[v];
+    }
+    return rp_chance(p, rp_philox(P->k0, P->k1, i, day, RP_P_HOSPITAL, 0).v[0]);
+}
+
+__global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *ev = reinterpret_cast<uint64_t *>(smem);               // [M2]
+    __shared__ int s_b, s_c;
+    const int tid = threadIdx.x;
+    int M = B.control[REINA_L_HOSP];
+    if (M > REINA_MAX_HOSP_EVENTS) M = REINA_MAX_HOSP_EVENTS;
+    if (M == 0) return;
+    int M2 = 1;
+    while (M2 < M) M2 <<= 1;
+    uint8_t *flag = smem + sizeof(uint64_t) * M2;                    // [M] success flags
+    const int b0 = B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)], c0 = B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)];
+    const bool ordered = !(b0 >= B.control[REINA_L_HOSP_ADMIT] && c0 >= B.control[REINA_L_ICU_ADMIT]);
+    for (int k = tid; k < M2; k += HOSP_THREADS) ev[k] = k < M ? B.hosp_events[k] : ~0ull;
+    __syncthreads();
+    if (ordered) {
+        for (int size = 2; size <= M2; size <<= 1) {
+            for (int strd = size >> 1; strd > 0; strd >>= 1) {
+                for (int k = tid; k < M2; k += HOSP_THREADS) {
+                    int partner = k ^ strd;
+                    if (partner > k) {
+                        bool up = (k & size) == 0;
+                        uint64_t a = ev[k], b = ev[partner];
+                        if ((a > b) == up) {
+                            ev[k] = b;
+                            ev[partner] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            int b = b0, c = c0;
+            for (int k = 0; k < M; k++) {
+                int type = (int)(ev[k] & 3);
+                uint8_t ok = 1;
+                if (type == EV_HOSPITALIZE) {
+                    if (b == 0) ok = 0; else b--;
+                } else if (type == EV_TO_ICU) {
+                    b++;
+                    if (c == 0) ok = 0; else c--;
+                } else if (type == EV_RELEASE_WARD) {
+                    b++;
+                } else {
+                    c++;
+                }
+                flag[k] = ok;
+            }
+            s_b = b;
+            s_c = c;
+        }
+    } else {
+        if (tid == 0) {
+            s_b = b0;
+            s_c = c0;
+        }
+        __syncthreads();
+        int db = 0, dc = 0;
+        for (int k = tid; k < M; k += HOSP_THREADS) {
+            int type = (int)(ev[k] & 3);
+            flag[k] = 1;
+            if (type == EV_HOSPITALIZE) db--;
+            else if (type == EV_TO_ICU) { db++; dc--; }
+            else if (type == EV_RELEASE_WARD) db++;
+            else dc++;
+        }
+        if (db) atomicAdd(&s_b, db);
+        if (dc) atomicAdd(&s_c, dc);
+    }
+    __syncthreads();
+    const reina_disease_t &d = P->dis;
+    for (int k = tid; k < M; k += HOSP_THREADS) {
+        uint64_t e = ev[k];
+        int type = (int)(e & 3);
+        uint32_t i = (uint32_t)((e >> 2) & 0xFFFFFFFFu);
+        uint32_t w = B.hot[i];
+        int age = age_of(P->age_start, i, 0, (int)P->nr_ages - 1), v = RH_VARIANT(w), sev = RH_SEV(w);
+        float od = B.onset_days[i];
+        int died = -1;  // -1 stays in care, 0 recovers, 1 dies
+        if (type == EV_HOSPITALIZE) {
+            if (!(w & RH_DETECTED)) {
+                w |= RH_DETECTED;
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, age)], 1);
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, age)], 1);
+            }
+            if (!flag[k]) {
+                died = dies_in_hospital(P, i, dp.day, sev, v, 0);
+            } else {
+                float f;
+                if (sev == RV_SEVERE)
+                    f = od * (1.0f - d.ratio_of_duration_before_hospitalisation[v]);
+                else
+                    f = od * d.ratio_of_duration_in_ward[v];
+                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(B.counters, rp_round_to_int(f)));
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_HOSPITALIZED, age)], 1);
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_WARD, age)], 1);
+            }
+        } else if (type == EV_TO_ICU) {
+            if (!flag[k] && dies_in_hospital(P, i, dp.day, sev, v, 0)) {
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_WARD, age)], -1);
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_HOSPITALIZED, age)], -1);
+                died = 1;
+            } else {
+                float f = 1.0f - d.ratio_of_duration_in_ward[v] - d.ratio_of_duration_before_hospitalisation[v];
+                f *= od;
+                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(B.counters, rp_round_to_int(f)));
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_WARD, age)], -1);
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_ICU, age)], 1);
+                atomicAdd(&B.counters[CNT_IDX(REINA_C_CUM_ICU, age)], 1);
+            }
+        } else if (type == EV_RELEASE_WARD) {
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_WARD, age)], -1);
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_HOSPITALIZED, age)], -1);
+            died = dies_in_hospital(P, i, dp.day, sev, v, 1);
+        } else {
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_ICU, age)], -1);
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_HOSPITALIZED, age)], -1);
+            died = dies_in_hospital(P, i, dp.day, sev, v, 1);
+        }
+        if (died == 1) {
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_INFECTED, age)], -1);
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_DEAD, age)], 1);
+            if (w & RH_POD_OUTSIDE) atomicAdd(&B.counters[CNT_IDX(REINA_C_NON_HOSPITAL_DEATHS, age)], 1);
+            w = RH_SET_STATE(w, RS_DEAD) & ~RH_HASLIST;
+        } else if (died == 0) {
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_INFECTED, age)], -1);
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_RECOVERED, age)], 1);
+            w = RH_SET_STATE(w, RS_RECOVERED) & ~RH_HASLIST;
+        }
+        B.hot[i] = w;
+    }
+    if (tid == 0) {
+        B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] = s_b;
+        B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] = s_c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_contacts: get_one_contact / get_person_from_age_range / person_expose / did_infect
+// (main.pyx:1290-1304,1525-1535,238-244,908-934), one lane per sampled contact.
+// Each wave takes 64 work items, prefix-sums their contact counts across lanes and spreads the
+// contacts evenly over its lanes.  Contact tables are staged in LDS once per workgroup.
+#define CON_THREADS 1024
+#define CON_WAVES (CON_THREADS / 64)
+
+struct ConShared {
+    uint32_t thr[REINA_MAX_AGES][REINA_MAX_ENTRIES];
+    uint32_t meta[REINA_MAX_AGES][REINA_MAX_ENTRIES];
+    float mask_p[REINA_MAX_AGES][8];
+    float p_sus[REINA_MAX_VARIANTS][REINA_MAX_AGES];
+    int32_t age_start[REINA_MAX_AGES + 1];
+    int32_t tcount[REINA_MAX_AGES];
+    uint32_t pre[CON_WAVES][64];        // inclusive prefix of contact counts per wave batch
+    uint4 item[CON_WAVES][64];          // the wave's current 64 work items
+    int32_t daily[REINA_NR_PLACES];
+    int32_t n_contacts;
+};
+
+__global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, const Tables *T, reina_buffers_t B, reina_day_t dp) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    ConShared &S = *reinterpret_cast<ConShared *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = B.control[REINA_L_WORK];
+    if ((int)(blockIdx.x * CON_WAVES * 64) >= W) return;  // no batch for this workgroup
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(T);
+        uint4 *dst = reinterpret_cast<uint4 *>(&S.thr[0][0]);
+        const int n16 = (int)(sizeof(Tables) / 16);
+        for (int k = tid; k < n16; k += CON_THREADS) dst[k] = src[k];
+        for (int k = tid; k < REINA_MAX_AGES * 8; k += CON_THREADS) (&S.mask_p[0][0])[k] = (&P->mask_p[0][0])[k];
+        for (int k = tid; k < REINA_MAX_VARIANTS * REINA_MAX_AGES; k += CON_THREADS) (&S.p_sus[0][0])[k] = (&P->dis.p_susceptibility[0][0])[k];
+        for (int k = tid; k <= REINA_MAX_AGES; k += CON_THREADS) S.age_start[k] = P->age_start[k];
+        for (int k = tid; k < REINA_MAX_AGES; k += CON_THREADS) S.tcount[k] = P->tcount[k];
+        if (tid < REINA_NR_PLACES) S.daily[tid] = 0;
+        if (tid == 0) S.n_contacts = 0;
+    }
+    __syncthreads();
+    const reina_disease_t &d = P->dis;
+    const uint4 *items = reinterpret_cast<const uint4 *>(B.work_items);
+    const int total_waves = gridDim.x * CON_WAVES;
+    for (int batch = blockIdx.x * CON_WAVES + wave; batch * 64 < W; batch += total_waves) {
+        const int idx = batch * 64 + lane;
+        uint4 it = make_uint4(0, 0, 0, 0);
+        if (idx < W) it = items[idx];
+        uint32_t nr = it.y & 0xFFu;
+        // inclusive prefix sum of nr across the wave
+        uint32_t inc = nr;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        S.pre[wave][lane] = inc;
+        S.item[wave][lane] = it;
+        const uint32_t total = __shfl(inc, 63);
+        // wave-private LDS row: same-wave visibility only needs the LDS write to have landed
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = lane; j < total; j += 64) {
+            // owner item: first lane whose inclusive prefix exceeds j
+            int lo = 0, hi = 63;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (S.pre[wave][mid] > j) hi = mid; else lo = mid + 1;
+            }
+            const int owner = lo;
+            const uint32_t c = j - (owner ? S.pre[wave][owner - 1] : 0u);
+            const uint4 own = S.item[wave][owner];  // (a shuffle would read 0 from lanes idle in the tail)
+            const uint32_t src = own.x;
+            const uint32_t packed = own.y;
+            const float src_inf = rp_u2f(own.z);
+            const int v = (int)((packed >> 8) & 0xFFu), row = (int)(packed >> 16);
+            rp_u4 r = rp_philox(P->k0, P->k1, src, dp.day, RP_P_CONTACT, c);
+            // first entry with r0 < threshold (thresholds are non-decreasing); none -> last entry
+            const int cnt = S.tcount[row];
+            int l2 = 0, h2 = cnt - 1;
+            while (l2 < h2) {
+                int mid = (l2 + h2) >> 1;
+                if (r.v[0] < S.thr[row][mid]) h2 = mid; else l2 = mid + 1;
+            }
+            const uint32_t m = S.meta[row][l2];
+            const int place = (int)(m & 0xFFu), cmin = (int)((m >> 8) & 0xFFu), cmax = (int)((m >> 16) & 0xFFu);
+            const uint32_t start = (uint32_t)S.age_start[cmin], end = (uint32_t)S.age_start[cmax + 1];
+            atomicAdd(&S.daily[place], 1);
+            if (end <= start) continue;
+            const uint32_t t = start + r.v[1] % (end - start);
+            const uint32_t wt = B.hot[t];
+            if (RH_STATE(wt) != RS_SUSCEPTIBLE) continue;
+            const int age_t = age_of(S.age_start, t, cmin, cmax);
+            float p = src_inf * S.p_sus[v][age_t] * d.infectiousness_multiplier[v];
+            if (!rp_chance(p, r.v[2])) continue;
+            const float mp = S.mask_p[row][place];
+            if (mp != 0.0f) {
+                float a = mp * d.p_mask_protects_others[v];
+                float b = mp * d.p_mask_protects_wearer[v];
+                float pm = a + b - a * b;
+                if (rp_chance(pm, r.v[3])) continue;
+            }
+            const uint32_t prio = rp_priority20(P->k0, P->k1, src, dp.day);
+            atomicMin((unsigned long long *)&B.claim[t], (unsigned long long)rp_order_key(dp.day, prio, src));
+            uint32_t pos = wave_alloc(&B.control[REINA_L_CAND]);
+            if (pos >= P->max_candidates) {
+                set_problem(B.counters, REINA_PROBLEM_CANDIDATE_OVERFLOW);
+                continue;
+            }
+            reinterpret_cast<uint4 *>(B.candidates)[pos] = make_uint4(t, src, (uint32_t)v, prio);
+        }
+        if (lane == 0 && total) atomicAdd(&S.n_contacts, (int)total);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (tid < REINA_NR_PLACES && S.daily[tid]) atomicAdd(&B.counters[SC_IDX(REINA_S_DAILY_CONTACTS + tid)], S.daily[tid]);
+    if (tid == 0 && S.n_contacts) atomicAdd(&B.control[REINA_L_CONTACTS], S.n_contacts);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_install: the attempt whose source holds the smallest (priority, id) key per target wins
+// (the reference: first source in rotated scan order, main.pyx:1982-1992) and infects it.
+__global__ void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    const int C = min(B.control[REINA_L_CAND], (int)P->max_candidates);
+    const uint4 *cand = reinterpret_cast<const uint4 *>(B.candidates);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < C; k += gridDim.x * blockDim.x) {
+        uint4 cd = cand[k];
+        if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
+        uint32_t w = ld_hot(&B.hot[cd.x]);
+        if (RH_STATE(w) != RS_SUSCEPTIBLE) continue;  // duplicate record of the same winner
+        install_infection(P, B, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode);
+    }
+}
+
+__global__ void k_day_end(reina_buffers_t B, reina_day_t dp) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        B.counters[SC_IDX(REINA_S_DAY)] = (int32_t)dp.day + 1;
+        B.counters[SC_IDX(REINA_S_QUEUE_LEN)] = B.control[((dp.day & 1) ^ 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+static int grid_for(uint32_t n_items, int threads, int max_blocks) {
+    long blocks = ((long)n_items + threads - 1) / threads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > max_blocks) blocks = max_blocks;
+    return (int)blocks;
+}
+
+static size_t take_event(reina_engine *e) {
+    if (e->ev_used == e->ev_pool.size()) {
+        hipEvent_t ev;
+        hipEventCreate(&ev);
+        e->ev_pool.push_back(ev);
+    }
+    return e->ev_used++;
+}
+
+static void resolve_profile(reina_engine *e) {
+    for (auto &p : e->scan_pairs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->ev_pool[p.first], e->ev_pool[p.second]) == hipSuccess) {
+            e->scan_ms += ms;
+            e->scan_launches++;
+        }
+    }
+    for (auto &p : e->day_pairs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->ev_pool[p.first], e->ev_pool[p.second]) == hipSuccess) e->all_ms += ms;
+    }
+    e->scan_pairs.clear();
+    e->day_pairs.clear();
+    e->ev_used = 0;
+}
+
+extern "C" {
+
+int reina_abi_version(void) { return 1; }
+const char *reina_last_error(void) { return g_last_error.c_str(); }
+
+int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, reina_engine_t **out) {
+    if (!cfg || !disease || !out) return REINA_E_INVALID;
+    if (cfg->nr_ages == 0 || cfg->nr_ages > REINA_MAX_AGES || cfg->nr_variants == 0 ||
+        cfg->nr_variants > REINA_MAX_VARIANTS) {
+        g_last_error = "nr_ages / nr_variants out of range";
+        return REINA_E_INVALID;
+    }
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) {
+        g_last_error = "no HIP device";
+        return REINA_E_HIP;
+    }
+    reina_engine *e = new reina_engine();
+    e->cfg = *cfg;
+    std::memset(&e->h_params, 0, sizeof(DevParams));
+    std::memset(&e->h_tables, 0, sizeof(Tables));
+    e->h_params.dis = *disease;
+    std::memcpy(e->h_params.age_start, cfg->age_start, sizeof(cfg->age_start));
+    e->h_params.n_agents = cfg->n_agents;
+    e->h_params.nr_ages = cfg->nr_ages;
+    e->h_params.nr_variants = cfg->nr_variants;
+    e->h_params.k0 = (uint32_t)cfg->seed;
+    e->h_params.k1 = (uint32_t)(cfg->seed >> 32);
+    e->h_params.max_work_items = cfg->max_work_items;
+    e->h_params.max_candidates = cfg->max_candidates;
+    e->h_params.max_queue = cfg->max_queue;
+    HIP_CHECK(hipMalloc(&e->d_params, sizeof(DevParams)));
+    HIP_CHECK(hipMalloc(&e->d_tables, sizeof(Tables)));
+    HIP_CHECK(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sizeof(ConShared)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hospital), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(REINA_MAX_HOSP_EVENTS * 9)));
+    *out = e;
+    return REINA_OK;
+}
+
+int reina_destroy(reina_engine_t *e) {
+    if (!e) return REINA_E_INVALID;
+    for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    hipFree(e->d_params);
+    hipFree(e->d_tables);
+    delete e;
+    return REINA_OK;
+}
+
+int reina_bind_buffers(reina_engine_t *e, const reina_buffers_t *b) {
+    if (!e || !b) return REINA_E_INVALID;
+    const void *const *p = reinterpret_cast<const void *const *>(b);
+    for (size_t k = 0; k < sizeof(reina_buffers_t) / sizeof(void *); k++)
+        if (!p[k]) {
+            g_last_error = "null buffer pointer";
+            return REINA_E_INVALID;
+        }
+    e->buf = *b;
+    e->bound = true;
+    return REINA_OK;
+}
+
+int reina_init_state(reina_engine_t *e, int32_t beds, int32_t icu, void *stream) {
+    if (!e || !e->bound) return REINA_E_NOT_BOUND;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_init, dim3(grid_for(e->cfg.n_agents, 256, 4096)), dim3(256), 0, s, e->d_params, e->buf, beds, icu);
+    HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+
+int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t *t, void *stream) {
+    if (!e || !t) return REINA_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t A = e->cfg.nr_ages;
+    std::memcpy(e->h_params.nrc, t->nr_contacts_by_age, sizeof(float) * A);
+    std::memcpy(e->h_params.tcount, t->count, sizeof(int32_t) * A);
+    std::memcpy(e->h_params.mask_p, t->mask_p, sizeof(float) * A * 8);
+    std::memcpy(e->h_tables.thr, t->threshold, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
+    std::memcpy(e->h_tables.meta, t->meta, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
+    // pageable source: the runtime stages the bytes before returning, so the host copies above
+    // may be overwritten by the next upload while earlier days are still queued on the stream
+    HIP_CHECK(hipMemcpyAsync(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice, s));
+    return REINA_OK;
+}
+
+int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
+    if (!e || !day) return REINA_E_INVALID;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    hipStream_t s = (hipStream_t)stream;
+    const reina_day_t dp = *day;
+    const uint32_t N = e->cfg.n_agents;
+    size_t ev_day0 = 0, ev_s0 = 0, ev_s1 = 0;
+    if (e->profile) {
+        ev_day0 = take_event(e);
+        hipEventRecord(e->ev_pool[ev_day0], s);
+    }
+    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
+    if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
+    if (e->testing_ever) {
+        const int g = grid_for(N / 64 + 1, 256, 256);
+        hipLaunchKernelGGL(k_test_detect, dim3(g), dim3(256), 0, s, e->d_params, e->buf, dp);
+        if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
+            hipLaunchKernelGGL(k_test_trace<0>, dim3(g), dim3(256), 0, s, e->d_params, e->buf, dp);
+            hipLaunchKernelGGL(k_test_trace<1>, dim3(g), dim3(256), 0, s, e->d_params, e->buf, dp);
+        }
+        hipLaunchKernelGGL(k_test_finish, dim3(1), dim3(64), 0, s, e->buf, dp);
+    }
+    if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
+    if (e->profile) {
+        ev_s0 = take_event(e);
+        hipEventRecord(e->ev_pool[ev_s0], s);
+    }
+    hipLaunchKernelGGL(k_scan, dim3(grid_for(N / 4 + 1, SCAN_THREADS, 2048)), dim3(SCAN_THREADS), 0, s, e->d_params, e->buf, dp);
+    if (e->profile) {
+        ev_s1 = take_event(e);
+        hipEventRecord(e->ev_pool[ev_s1], s);
+        e->scan_pairs.emplace_back(ev_s0, ev_s1);
+    }
+    hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 9, s, e->d_params, e->buf, dp);
+    hipLaunchKernelGGL(k_contacts, dim3(grid_for(N / 16 + 1, CON_THREADS, 256)), dim3(CON_THREADS), sizeof(ConShared), s,
+                       e->d_params, e->d_tables, e->buf, dp);
+    hipLaunchKernelGGL(k_install, dim3(grid_for(N / 64 + 1, 256, 512)), dim3(256), 0, s, e->d_params, e->buf, dp);
+    hipLaunchKernelGGL(k_day_end, dim3(1), dim3(64), 0, s, e->buf, dp);
+    if (e->profile) {
+        size_t ev_day1 = take_event(e);
+        hipEventRecord(e->ev_pool[ev_day1], s);
+        e->day_pairs.emplace_back(ev_day0, ev_day1);
+    }
+    HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+
+int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, void *stream) {
+    for (uint32_t k = 0; k < n_days; k++) {
+        int rc = reina_step_day(e, &days[k], stream);
+        if (rc) return rc;
+    }
+    return REINA_OK;
+}
+
+int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream) {
+    if (!e || !out_host) return REINA_E_INVALID;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_CHECK(hipMemcpyAsync(out_host, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return REINA_OK;
+}
+
+int reina_profile_enable(reina_engine_t *e, int enable) {
+    if (!e) return REINA_E_INVALID;
+    e->profile = enable != 0;
+    return REINA_OK;
+}
+
+int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_launches, double *all_ms_total) {
+    if (!e) return REINA_E_INVALID;
+    HIP_CHECK(hipDeviceSynchronize());
+    resolve_profile(e);
+    if (scan_ms_total) *scan_ms_total = e->scan_ms;
+    if (scan_launches) *scan_launches = e->scan_launches;
+    if (all_ms_total) *all_ms_total = e->all_ms;
+    e->scan_ms = 0;
+    e->all_ms = 0;
+    e->scan_launches = 0;
+    return REINA_OK;
+}
+
+}  // extern "C"

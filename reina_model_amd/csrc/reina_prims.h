@@ -1,0 +1,245 @@
+// reina_prims.h -- numeric primitives of the parallel day step.
+//
+// Compiled by hipcc (device code, gfx950) AND by gcc (oracle/reina_par.c, the CPU checker).
+// Everything here is built from IEEE-754 basic operations only (+ - * / sqrt, integer ops) with
+// FP contraction disabled on both compilers, so a value computed on a CDNA4 lane and on a host
+// core is bit-identical by construction: no libm, no native exp/log, no fma.
+//
+// The parallel engine cannot consume the reference's single PCG64 stream in scan order
+// (cythonsim/simrandom.pyx:13-55 is inherently sequential), so every random decision is drawn
+// from Philox4x32-10 keyed by (seed) and counted by (who, day, purpose, block): the value a
+// decision sees is independent of thread scheduling, shard layout and launch geometry.
+#ifndef REINA_PRIMS_H
+#define REINA_PRIMS_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RP_HD __host__ __device__ __forceinline__
+#else
+#define RP_HD static inline
+#endif
+
+// ------------------------------------------------------------------ bit casts
+RP_HD float rp_u2f(uint32_t u) {
+    union { uint32_t u; float f; } c;
+    c.u = u;
+    return c.f;
+}
+RP_HD uint32_t rp_f2u(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    return c.u;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+typedef struct { uint32_t v[4]; } rp_u4;
+
+#define RP_PHILOX_M0 0xD2511F53u
+#define RP_PHILOX_M1 0xCD9E8D57u
+#define RP_PHILOX_W0 0x9E3779B9u
+#define RP_PHILOX_W1 0xBB67AE85u
+
+RP_HD rp_u4 rp_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)RP_PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)RP_PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += RP_PHILOX_W0;
+        k1 += RP_PHILOX_W1;
+    }
+    rp_u4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+// Purposes (counter word c2 low byte). The sub-index (contact number, import try, tracer id)
+// goes in c3 or the upper bits of c2; `who` (agent / event id) in c0, day in c1.
+enum {
+    RP_P_NRCONTACTS = 1,  // (agent, day): v[0] normal for the lognormal contact count
+    RP_P_CONTACT = 2,     // (agent, day, c3 = contact #): place/range, target, infect, mask
+    RP_P_INFECT = 3,      // (target, day, c3 = block): severity, incubation gamma
+    RP_P_ONSET = 4,       // (agent, day, c3 = block): onset->removed gamma; block 0 v[3] = "tested anyway"
+    RP_P_HOSPITAL = 5,    // (agent, day): no-bed / no-ICU death roll
+    RP_P_TRACE = 6,       // (candidate, day, c3 = tracer): contact-tracing success
+    RP_P_IMPORT = 7,      // (import #, day, c3 = try): age class, target
+    RP_P_PRIORITY = 8     // (agent, day): order key for scarce resources / winner selection
+};
+
+// uniform in [0,1) with 24 random bits: exact in float
+RP_HD float rp_uniform24(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// RandomPool.chance semantics (simrandom.pyx:32-39): p==1 -> true, p==0 -> false without
+// looking at the draw, else u < p.
+RP_HD int rp_chance(float p, uint32_t r) {
+    if (p == 1.0f) return 1;
+    if (p == 0.0f) return 0;
+    return rp_uniform24(r) < p;
+}
+
+// ------------------------------------------------------------------ exp / log (float, reproducible)
+// expf for |x| <= ~80. n = round(x*log2e); r = x - n*ln2 (two-term Cody-Waite); degree-6 poly.
+RP_HD float rp_expf(float x) {
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    float t = x * 1.44269504088896341f;
+    // round to nearest via floor(t + 0.5)
+    float tf = t + 0.5f;
+    int n = (int)tf;
+    if ((float)n > tf) n -= 1;  // floor for negatives
+    float fn = (float)n;
+    float r = x - fn * 0.693359375f;          // ln2_hi (exact in 10 bits)
+    r = r - fn * -2.12194440e-4f;             // ln2_lo
+    // e^r ~ 1 + r + r^2/2 + ... (|r| <= 0.3466)
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    float r2 = r * r;
+    float e = p * r2 + r + 1.0f;
+    // scale by 2^n (n in [-126,127] after the clamps above)
+    return e * rp_u2f((uint32_t)(n + 127) << 23);
+}
+
+// logf for finite x > 0 (normal numbers). m in [sqrt(1/2), sqrt(2)); log m = 2 atanh((m-1)/(m+1)).
+RP_HD float rp_logf(float x) {
+    uint32_t ux = rp_f2u(x);
+    int e = (int)(ux >> 23) - 127;
+    uint32_t mant = (ux & 0x007FFFFFu) | 0x3F800000u;
+    float m = rp_u2f(mant);
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float p = 0.11111111f;          // 1/9
+    p = p * z + 0.14285714f;        // 1/7
+    p = p * z + 0.2f;               // 1/5
+    p = p * z + 0.33333333f;        // 1/3
+    p = p * z + 1.0f;
+    float lm = 2.0f * s * p;
+    float fe = (float)e;
+    return (fe * 0.693359375f + lm) + fe * -2.12194440e-4f;
+}
+
+// ------------------------------------------------------------------ standard normal from one u32
+// Inverse-CDF (P. J. Acklam's rational approximation; |rel err| ~ 1e-9 in exact arithmetic,
+// ~1e-6 here). u is the centre of one of 2^32 equal cells of (0,1): never 0 or 1.
+RP_HD float rp_normal_from_u32(uint32_t r) {
+    // p = (r + 0.5) / 2^32 computed in two exact steps: hi 24 bits + low 8 bits
+    float p = ((float)(r >> 8) + ((float)(r & 0xFFu) + 0.5f) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);
+    // the rational polynomials have large alternating coefficients: evaluate them in double
+    // (IEEE basic ops, identical on host and device); log/sqrt of the tails stay in float
+    const double a0 = -3.969683028665376e+01, a1 = 2.209460984245205e+02, a2 = -2.759285104469687e+02,
+                 a3 = 1.383577518672690e+02, a4 = -3.066479806614716e+01, a5 = 2.506628277459239e+00;
+    const double b0 = -5.447609879822406e+01, b1 = 1.615858368580409e+02, b2 = -1.556989798598866e+02,
+                 b3 = 6.680131188771972e+01, b4 = -1.328068155288572e+01;
+    const double c0 = -7.784894002430293e-03, c1 = -3.223964580411365e-01, c2 = -2.400758277161838e+00,
+                 c3 = -2.549732539343734e+00, c4 = 4.374664141464968e+00, c5 = 2.938163982698783e+00;
+    const double d0 = 7.784695709041462e-03, d1 = 3.224671290700398e-01, d2 = 2.445134137142996e+00,
+                 d3 = 3.754408661907416e+00;
+    const float plow = 0.02425f;
+    float x;
+    if (p < plow) {
+        double q = (double)sqrtf(-2.0f * rp_logf(p));
+        x = (float)((((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) /
+                    ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0));
+    } else if (p <= 1.0f - plow) {
+        double q = (double)p - 0.5;
+        double t = q * q;
+        x = (float)((((((a0 * t + a1) * t + a2) * t + a3) * t + a4) * t + a5) * q /
+                    (((((b0 * t + b1) * t + b2) * t + b3) * t + b4) * t + 1.0));
+    } else {
+        // upper tail by symmetry on the exact complement cell: 1-p = ((2^32-1-r) + 0.5)/2^32
+        uint32_t rc = 0xFFFFFFFFu - r;
+        float pc = ((float)(rc >> 8) + ((float)(rc & 0xFFu) + 0.5f) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);
+        double q = (double)sqrtf(-2.0f * rp_logf(pc));
+        x = (float)(-(((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) /
+                    ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0));
+    }
+    return x;
+}
+
+// ------------------------------------------------------------------ gamma (Marsaglia-Tsang, shape >= 1)
+// RandomPool.gamma(mu, cv) (simrandom.pyx:46-55): sigma = cv*mu, theta = sigma^2/mu,
+// kappa = mu/theta; returns theta * Gamma(kappa).  Same construction numpy's random_gamma_f uses
+// (Marsaglia & Tsang 2000), on Philox blocks: block k (k = first_block, first_block+1, ...)
+// supplies two (normal, uniform) attempts.  Bounded at 32 blocks (P(reject 64x) < 1e-80).
+RP_HD float rp_gamma_mu_cv(float mu, float cv, uint32_t k0, uint32_t k1, uint32_t who, uint32_t day,
+                           uint32_t purpose, uint32_t first_block) {
+    float sigma = cv * mu;
+    float theta = (sigma * sigma) / mu;
+    float kappa = mu / theta;
+    float b = kappa - 1.0f / 3.0f;
+    float c = 1.0f / sqrtf(9.0f * b);
+    for (uint32_t blk = 0; blk < 32u; blk++) {
+        rp_u4 r = rp_philox(k0, k1, who, day, purpose, first_block + blk);
+        for (int h = 0; h < 2; h++) {
+            float X = rp_normal_from_u32(r.v[2 * h]);
+            float V = 1.0f + c * X;
+            if (V <= 0.0f) continue;
+            V = V * V * V;
+            float U = rp_uniform24(r.v[2 * h + 1]);
+            float X2 = X * X;
+            if (U < 1.0f - 0.0331f * X2 * X2) return theta * (b * V);
+            if (U > 0.0f && rp_logf(U) < 0.5f * X2 + b * (1.0f - V + rp_logf(V))) return theta * (b * V);
+        }
+    }
+    return theta * b;  // unreachable in practice
+}
+
+// round_to_int of the reference (main.pyx:773-774): (int)(f + 0.5)
+RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
+
+// ------------------------------------------------------------------ hot word (4 B per agent)
+//  bits  0-2  state            (main.pyx:41-48)
+//  bits  3-5  symptom severity (main.pyx:33-38)
+//  bit   6    was_detected
+//  bit   7    queued_for_testing
+//  bits  8-9  variant_idx
+//  bit   10   included_in_totals
+//  bit   11   place_of_death == DEATH_OUTSIDE_HOSPITAL
+//  bit   12   fresh: infected before today's scan (day_of_infection == today, main.pyx:402)
+//  bit   13   vaccinated (day_of_vaccination >= 0)
+//  bit   14   has infectee list (infected while contact tracing was on, main.pyx:227-233)
+//  bits 16-23 days_left (saturating 255)
+//  bits 24-31 day_of_illness (saturating 255)
+#define RH_STATE(w) ((w) & 7u)
+#define RH_SEV(w) (((w) >> 3) & 7u)
+#define RH_DETECTED 0x40u
+#define RH_QUEUED 0x80u
+#define RH_VARIANT(w) (((w) >> 8) & 3u)
+#define RH_INCLUDED 0x400u
+#define RH_POD_OUTSIDE 0x800u
+#define RH_FRESH 0x1000u
+#define RH_VACCINATED 0x2000u
+#define RH_HASLIST 0x4000u
+#define RH_DAYS_LEFT(w) (((w) >> 16) & 0xFFu)
+#define RH_DOI(w) ((w) >> 24)
+#define RH_SET_STATE(w, s) (((w) & ~7u) | (uint32_t)(s))
+#define RH_SET_DAYS_LEFT(w, d) (((w) & ~0x00FF0000u) | ((uint32_t)(d) << 16))
+#define RH_SET_DOI(w, d) (((w) & 0x00FFFFFFu) | ((uint32_t)(d) << 24))
+
+enum { RS_SUSCEPTIBLE = 0, RS_INCUBATION, RS_ILLNESS, RS_HOSPITALIZED, RS_IN_ICU, RS_RECOVERED, RS_DEAD };
+enum { RV_ASYMPTOMATIC = 0, RV_MILD, RV_SEVERE, RV_CRITICAL, RV_FATAL };
+enum { RT_NO_TESTING = 0, RT_ALL_WITH_SYMPTOMS_CT, RT_ALL_WITH_SYMPTOMS, RT_ONLY_SEVERE_SYMPTOMS };
+
+// claim / ordering key: smaller wins. [4095-day : 12][priority : 20][id : 32]
+RP_HD uint64_t rp_order_key(uint32_t day, uint32_t prio20, uint32_t id) {
+    return ((uint64_t)((4095u - day) & 0xFFFu) << 52) | ((uint64_t)(prio20 & 0xFFFFFu) << 32) | id;
+}
+RP_HD uint32_t rp_priority20(uint32_t k0, uint32_t k1, uint32_t who, uint32_t day) {
+    return rp_philox(k0, k1, who, day, RP_P_PRIORITY, 0).v[0] >> 12;
+}
+
+#endif  // REINA_PRIMS_H

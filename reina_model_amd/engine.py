@@ -1,0 +1,274 @@
+"""ctypes binding of the engine C ABI (include/reina_hip.h) + state allocation.
+
+`HipEngine` is the product path: it loads `csrc/libreina_hip.so` (hand-written HIP kernels for
+gfx950), allocates the per-agent SoA state as PyTorch-ROCm tensors in HBM and hands their device
+pointers to the library.  There is NO CPU fallback: if the shared library or a GPU is missing,
+construction raises.
+
+`Engine` itself is ABI-generic (library handle + symbol prefix + allocator) so the test-suite can
+drive another implementation of the same ABI -- the CPU checker under oracle/ -- through the
+identical host code.  Nothing in this package imports or references that checker.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(HERE, 'csrc', 'libreina_hip.so')
+
+MAX_AGES = 128
+MAX_VARIANTS = 4
+MAX_ENTRIES = 96
+NR_PLACES = 6
+IOT_LEN = 21
+MAX_IMPORT_CLASSES = 16
+MAX_IMPORT_BATCHES = 16
+MAX_VACCINATIONS = 16
+MAX_HOSP_EVENTS = 16384
+
+C_NAMES = ('infected', 'detected', 'all_detected', 'all_infected', 'in_ward', 'hospitalized',
+           'in_icu', 'cum_icu', 'dead', 'susceptible', 'recovered', 'vaccinated',
+           'non_hospital_deaths', 'new_infections')
+C_NR = len(C_NAMES)
+S_AVAILABLE_BEDS, S_AVAILABLE_ICU, S_BEDS, S_ICU_UNITS, S_TOTAL_INFECTIONS, S_TOTAL_INFECTORS, \
+    S_EXPOSED_PER_DAY, S_CT_CASES_PER_DAY, S_PROBLEM, S_DAY, S_UNABLE_TO_IMPORT, S_QUEUE_LEN = range(12)
+S_DAILY_CONTACTS = 16
+S_INFECTED_BY_VARIANT = 24
+S_NR = 32
+COUNTER_WORDS = C_NR * MAX_AGES + S_NR
+L_NR = 32
+
+ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'upload_contact_tables',
+                 'step_day', 'run_days', 'read_counters', 'profile_enable', 'profile_read',
+                 'last_error', 'abi_version')
+
+
+class Config(ctypes.Structure):
+    _fields_ = [('n_agents', ctypes.c_uint32), ('nr_ages', ctypes.c_uint32),
+                ('nr_variants', ctypes.c_uint32), ('reserved0', ctypes.c_uint32),
+                ('seed', ctypes.c_uint64),
+                ('max_work_items', ctypes.c_uint32), ('max_candidates', ctypes.c_uint32),
+                ('max_queue', ctypes.c_uint32), ('reserved1', ctypes.c_uint32),
+                ('age_start', ctypes.c_int32 * (MAX_AGES + 1))]
+
+
+_FV = ctypes.c_float * MAX_VARIANTS
+_FA = ctypes.c_float * MAX_AGES
+
+
+class Disease(ctypes.Structure):
+    _fields_ = [(n, _FV) for n in (
+        'infectiousness_multiplier', 'p_asymptomatic_infection', 'p_hospital_death_no_beds',
+        'p_icu_death_no_beds', 'mean_incubation_duration', 'mean_duration_from_onset_to_death',
+        'mean_duration_from_onset_to_recovery', 'ratio_of_duration_before_hospitalisation',
+        'ratio_of_duration_in_ward', 'p_mask_protects_others', 'p_mask_protects_wearer')] + [
+        ('infectiousness_over_time', (ctypes.c_float * (IOT_LEN + 3)) * MAX_VARIANTS),
+        ('p_susceptibility', _FA * MAX_VARIANTS),
+        ('p_symptomatic', _FA), ('p_severe_given_symptomatic', _FA),
+        ('p_critical_given_severe', _FA), ('p_fatal_given_critical', _FA),
+        ('p_death_outside_hospital', _FA),
+        ('n_import_classes', ctypes.c_uint32),
+        ('import_class_min_age', ctypes.c_int32 * MAX_IMPORT_CLASSES),
+        ('import_class_max_age', ctypes.c_int32 * MAX_IMPORT_CLASSES),
+        ('import_class_cum', ctypes.c_float * MAX_IMPORT_CLASSES)]
+
+
+class ContactTablesABI(ctypes.Structure):
+    _fields_ = [('nr_contacts_by_age', ctypes.c_void_p), ('count', ctypes.c_void_p),
+                ('threshold', ctypes.c_void_p), ('meta', ctypes.c_void_p),
+                ('mask_p', ctypes.c_void_p)]
+
+
+BUFFER_FIELDS = ('hot', 'infector', 'n_infected', 'onset_days', 'vacc_day', 'first_infectee',
+                 'next_sibling', 'claim', 'counters', 'control', 'work_items', 'candidates',
+                 'queue0', 'queue1', 'level1', 'hosp_events')
+
+
+class Buffers(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in BUFFER_FIELDS]
+
+
+class ImportBatch(ctypes.Structure):
+    _fields_ = [('count', ctypes.c_uint32), ('variant', ctypes.c_uint32),
+                ('pre_init', ctypes.c_uint32), ('reserved', ctypes.c_uint32)]
+
+
+class Vaccination(ctypes.Structure):
+    _fields_ = [('nr', ctypes.c_uint32), ('idx_start', ctypes.c_uint32),
+                ('idx_end', ctypes.c_uint32), ('slot', ctypes.c_uint32)]
+
+
+class Day(ctypes.Structure):
+    _fields_ = [('day', ctypes.c_uint32), ('testing_mode', ctypes.c_uint32),
+                ('p_detected_anyway', ctypes.c_float), ('p_successful_tracing', ctypes.c_float),
+                ('add_beds', ctypes.c_int32), ('add_icu_units', ctypes.c_int32),
+                ('n_import_batches', ctypes.c_uint32), ('n_vaccinations', ctypes.c_uint32),
+                ('import_batches', ImportBatch * MAX_IMPORT_BATCHES),
+                ('vaccinations', Vaccination * MAX_VACCINATIONS),
+                ('history_row', ctypes.c_void_p)]
+
+
+def bind_abi(lib, prefix):
+    """Resolve and type every ABI entry point; raises AttributeError if one is missing."""
+    f = {}
+    for name in ABI_FUNCTIONS:
+        f[name] = getattr(lib, prefix + name)
+    vp = ctypes.c_void_p
+    f['create'].argtypes = [ctypes.POINTER(Config), ctypes.POINTER(Disease), ctypes.POINTER(vp)]
+    f['destroy'].argtypes = [vp]
+    f['bind_buffers'].argtypes = [vp, ctypes.POINTER(Buffers)]
+    f['init_state'].argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp]
+    f['upload_contact_tables'].argtypes = [vp, ctypes.POINTER(ContactTablesABI), vp]
+    f['step_day'].argtypes = [vp, ctypes.POINTER(Day), vp]
+    f['run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp]
+    f['read_counters'].argtypes = [vp, vp, vp]
+    f['profile_enable'].argtypes = [vp, ctypes.c_int]
+    f['profile_read'].argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
+                                  ctypes.POINTER(ctypes.c_double)]
+    f['last_error'].restype = ctypes.c_char_p
+    f['last_error'].argtypes = []
+    f['abi_version'].argtypes = []
+    for name in ABI_FUNCTIONS:
+        if name != 'last_error':
+            f[name].restype = ctypes.c_int
+    return f
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class NumpyAllocator:
+    """Host-memory allocator (used by the test-suite to drive a CPU implementation of the ABI)."""
+    device = 'cpu'
+
+    def zeros(self, n, dtype):
+        return np.zeros(n, dtype=dtype)
+
+    def ptr(self, arr):
+        return arr.ctypes.data
+
+    def stream(self):
+        return None
+
+    def to_host(self, arr):
+        return np.array(arr, copy=True)
+
+
+class TorchAllocator:
+    """HBM allocator: state lives in PyTorch-ROCm tensors, the library sees raw device pointers."""
+
+    def __init__(self, device='cuda:0'):
+        import torch
+        if not torch.cuda.is_available():
+            raise EngineError('no GPU visible to PyTorch-ROCm: the HIP engine has no CPU fallback')
+        self.torch = torch
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self._np2t = {np.uint32: torch.int32, np.int32: torch.int32, np.float32: torch.float32,
+                      np.uint64: torch.int64, np.int64: torch.int64}
+
+    def zeros(self, n, dtype):
+        return self.torch.zeros(int(n), dtype=self._np2t[dtype], device=self.device)
+
+    def ptr(self, t):
+        return t.data_ptr()
+
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def to_host(self, t):
+        return t.cpu().numpy()
+
+
+class Engine:
+    """One engine instance = one shard of agents on one device."""
+
+    def __init__(self, lib, prefix, allocator, config, disease):
+        self.f = bind_abi(lib, prefix)
+        self.alloc = allocator
+        self.config = config
+        self._h = ctypes.c_void_p()
+        self._check(self.f['create'](ctypes.byref(config), ctypes.byref(disease), ctypes.byref(self._h)), 'create')
+        n = config.n_agents
+        a = allocator
+        self.tensors = dict(
+            hot=a.zeros(n, np.uint32), infector=a.zeros(n, np.int32), n_infected=a.zeros(n, np.int32),
+            onset_days=a.zeros(n, np.float32), vacc_day=a.zeros(n, np.int32),
+            first_infectee=a.zeros(n, np.int32), next_sibling=a.zeros(n, np.int32),
+            claim=a.zeros(n, np.uint64), counters=a.zeros(COUNTER_WORDS, np.int32),
+            control=a.zeros(L_NR, np.int32),
+            work_items=a.zeros(4 * config.max_work_items, np.uint32),
+            candidates=a.zeros(4 * config.max_candidates, np.uint32),
+            queue0=a.zeros(config.max_queue, np.uint32), queue1=a.zeros(config.max_queue, np.uint32),
+            level1=a.zeros(config.max_queue, np.uint32), hosp_events=a.zeros(MAX_HOSP_EVENTS, np.uint64),
+        )
+        bufs = Buffers(**{k: a.ptr(v) for k, v in self.tensors.items()})
+        self._check(self.f['bind_buffers'](self._h, ctypes.byref(bufs)), 'bind_buffers')
+        self._keep = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.f['last_error']()
+            raise EngineError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+    def close(self):
+        if self._h:
+            self.f['destroy'](self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init_state(self, beds, icu_units):
+        self._check(self.f['init_state'](self._h, int(beds), int(icu_units), self.alloc.stream()), 'init_state')
+
+    def upload_contact_tables(self, nrc, count, threshold, meta, mask_p):
+        arrs = [np.ascontiguousarray(nrc, dtype=np.float32), np.ascontiguousarray(count, dtype=np.int32),
+                np.ascontiguousarray(threshold, dtype=np.uint32), np.ascontiguousarray(meta, dtype=np.uint32),
+                np.ascontiguousarray(mask_p, dtype=np.float32)]
+        t = ContactTablesABI(*[x.ctypes.data for x in arrs])
+        self._check(self.f['upload_contact_tables'](self._h, ctypes.byref(t), self.alloc.stream()), 'upload_contact_tables')
+
+    def step_day(self, day):
+        self._check(self.f['step_day'](self._h, ctypes.byref(day), self.alloc.stream()), 'step_day')
+
+    def run_days(self, days):
+        arr = (Day * len(days))(*days)
+        self._check(self.f['run_days'](self._h, arr, len(days), self.alloc.stream()), 'run_days')
+
+    def read_counters(self):
+        out = np.zeros(COUNTER_WORDS, dtype=np.int32)
+        self._check(self.f['read_counters'](self._h, out.ctypes.data, self.alloc.stream()), 'read_counters')
+        return out
+
+    def profile_enable(self, on=True):
+        self._check(self.f['profile_enable'](self._h, 1 if on else 0), 'profile_enable')
+
+    def profile_read(self):
+        a, b, c = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_double()
+        self._check(self.f['profile_read'](self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), 'profile_read')
+        return dict(scan_ms_total=a.value, scan_launches=b.value, all_ms_total=c.value)
+
+
+_hip_lib = None
+
+
+def load_hip_library():
+    """dlopen csrc/libreina_hip.so; loud failure when it has not been built (see
+    __graft_entry__.build / reina_model_amd/build.py)."""
+    global _hip_lib
+    if _hip_lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise EngineError('HIP extension missing: %s (run `python -m reina_model_amd.build`); '
+                              'there is no CPU fallback' % HIP_LIB_PATH)
+        _hip_lib = ctypes.CDLL(HIP_LIB_PATH)
+    return _hip_lib
+
+
+def hip_engine(config, disease, device='cuda:0'):
+    return Engine(load_hip_library(), 'reina_', TorchAllocator(device), config, disease)

@@ -1,0 +1,470 @@
+"""Drop-in for the reference's `cythonsim.model` module (cythonsim/main.pyx), MI355X-native.
+
+Exports the names `calc/simulation.py` uses -- `Context`, `DISEASE_PARAMS`, `SEVERITY_TO_STR`,
+`SimulationFailed`, `__file__` -- with the same constructor signature, `add_intervention`,
+`generate_state`, `iterate`, `apply_intervention`, `get_population_stats`,
+`get_date_for_today` protocol (main.pyx:1759-1960, 2011-2018).  Agent state lives in HBM as SoA
+PyTorch-ROCm tensors; every day step is a handful of hand-written HIP kernels behind the C ABI
+of include/reina_hip.h.  Host-level work the reference also does in Python stays here:
+intervention dispatch, the contact-table rebuild, weekly-import bookkeeping.
+
+Differences a caller can observe (DESIGN.md "Parity tiers"):
+  * agents are stored sorted by age (the reference shuffles agent ids; ids are never exported);
+  * random decisions are Philox-keyed per (agent, day, purpose) instead of one sequential PCG64
+    stream, so a given seed yields a different but statistically equivalent trajectory;
+  * `iterate()` only enqueues GPU work; problems surface at the next `generate_state()` /
+    `synchronize()` (the reference raises at the end of `iterate()`, main.pyx:2017-2018).
+"""
+import ctypes
+from datetime import date, timedelta
+
+import numpy as np
+
+from . import engine as _eng
+from .contacts import ContactMatrix, PLACES
+
+# main.pyx:777-785
+DISEASE_PARAMS = (
+    'p_susceptibility', 'p_symptomatic', 'p_severe', 'p_critical',
+    'p_fatal', 'p_hospital_death_no_beds', 'p_icu_death_no_beds',
+    'p_death_outside_hospital', 'p_asymptomatic_infection',
+    'infectiousness_multiplier', 'mean_incubation_duration',
+    'mean_duration_from_onset_to_death', 'mean_duration_from_onset_to_recovery',
+    'ratio_of_duration_before_hospitalisation', 'ratio_of_duration_in_ward',
+    'p_mask_protects_wearer', 'p_mask_protects_others', 'variants',
+)
+# main.pyx:101-108
+SEVERITY_TO_STR = {0: 'ASYMPTOMATIC', 1: 'MILD', 2: 'SEVERE', 3: 'CRITICAL', 4: 'FATAL'}
+STR_TO_SEVERITY = {v: k for k, v in SEVERITY_TO_STR.items()}
+# main.pyx:110-121 (+ this engine's capacity overflows, include/reina_hip.h)
+PROBLEM_TO_STR = {
+    0: 'No problemos', 1: 'Too many infectees', 2: 'Too many contacts',
+    3: 'Hospital accounting failure', 4: 'Negative number of contacts', 5: 'Malloc failure',
+    6: 'Other failure', 7: 'Wrong state', 8: 'Contact probability failure', 9: 'Infectees mismatch',
+    100: 'Work list overflow', 101: 'Candidate list overflow', 102: 'Testing queue overflow',
+    103: 'Hospital event list overflow', 104: 'Day counter overflow',
+}
+# main.pyx:660-682: infectiousness by day relative to symptom onset (Luca et al. 2020)
+INFECTIOUSNESS_OVER_TIME = (
+    (-10, 0.00183), (-9, 0.00280), (-8, 0.00446), (-7, 0.00742), (-6, 0.01291), (-5, 0.02350),
+    (-4, 0.04419), (-3, 0.08247), (-2, 0.14018), (-1, 0.19032), (0, 0.18539), (1, 0.13091),
+    (2, 0.07538), (3, 0.04018), (4, 0.02144), (5, 0.01185), (6, 0.00686), (7, 0.00415),
+    (8, 0.00262), (9, 0.00172), (10, 0.00117),
+)
+NO_TESTING, ALL_WITH_SYMPTOMS_CT, ALL_WITH_SYMPTOMS, ONLY_SEVERE_SYMPTOMS = 0, 1, 2, 3  # main.pyx:441-445
+
+POP_ATTRS = ('susceptible', 'vaccinated', 'infected', 'all_infected', 'detected', 'all_detected',
+             'in_icu', 'cum_icu', 'in_ward', 'dead', 'recovered', 'non_hospital_deaths',
+             'new_infections')  # generate_state order, main.pyx:1819-1833
+
+
+class SimulationFailed(Exception):
+    pass
+
+
+def _expand_lte(pairs, nr_ages):
+    """ClassifiedValues + cv_get_greatest_lte (main.pyx:684-730) expanded to one float32 per age."""
+    classes = [int(p[0]) for p in pairs]
+    values = np.asarray([p[1] for p in pairs], dtype=np.float64).astype(np.float32)
+    if classes[0] > 0:
+        raise ValueError('first age class must be 0 (the reference reads out of bounds otherwise)')
+    out = np.zeros(_eng.MAX_AGES, dtype=np.float32)
+    for age in range(nr_ages):
+        idx = len(classes) - 1
+        for i, c in enumerate(classes):
+            if c > age:
+                idx = i - 1
+                break
+        out[age] = values[idx]
+    return out
+
+
+def _cv_div(a, b):
+    # main.pyx:808-817, Python double division before the float32 store
+    assert [x[0] for x in a] == [x[0] for x in b]
+    return [(x[0], x[1] / y[1]) for x, y in zip(a, b)]
+
+
+def build_disease_struct(disease_params, nr_ages, imported_infection_ages):
+    """Disease.__init__ / variant_init (main.pyx:820-881) -> reina_disease_t."""
+    d = _eng.Disease()
+    variants = [dict(disease_params)]
+    names = ['wild-type']
+    for v in disease_params['variants']:
+        p = dict(disease_params)
+        p.update(v)
+        variants.append(p)
+        names.append(v['name'])
+    if len(variants) > _eng.MAX_VARIANTS:
+        raise ValueError('at most %d variants' % _eng.MAX_VARIANTS)
+    scalar_fields = ('infectiousness_multiplier', 'p_asymptomatic_infection', 'p_hospital_death_no_beds',
+                     'p_icu_death_no_beds', 'mean_incubation_duration', 'mean_duration_from_onset_to_death',
+                     'mean_duration_from_onset_to_recovery', 'ratio_of_duration_before_hospitalisation',
+                     'ratio_of_duration_in_ward', 'p_mask_protects_others', 'p_mask_protects_wearer')
+    for vi, p in enumerate(variants):
+        for f in scalar_fields:
+            getattr(d, f)[vi] = float(np.float32(p[f]))
+        for k, (day, val) in enumerate(INFECTIOUSNESS_OVER_TIME):
+            d.infectiousness_over_time[vi][k] = float(np.float32(val))
+        sus = _expand_lte(p['p_susceptibility'], nr_ages)
+        for a in range(nr_ages):
+            d.p_susceptibility[vi][a] = float(sus[a])
+    base = variants[0]
+    sym = [tuple(x) for x in base['p_symptomatic']]
+    sev = [tuple(x) for x in base['p_severe']]
+    cri = [tuple(x) for x in base['p_critical']]
+    fat = [tuple(x) for x in base['p_fatal']]
+    for field, pairs in (('p_symptomatic', sym), ('p_severe_given_symptomatic', _cv_div(sev, sym)),
+                         ('p_critical_given_severe', _cv_div(cri, sev)),
+                         ('p_fatal_given_critical', _cv_div(fat, cri)),
+                         ('p_death_outside_hospital', base['p_death_outside_hospital'])):
+        arr = _expand_lte(pairs, nr_ages)
+        tgt = getattr(d, field)
+        for a in range(nr_ages):
+            tgt[a] = float(arr[a])
+    # imported_infection_ages -> cumulative float32 weights (main.pyx:1376-1384)
+    wsum = sum([x[1] for x in imported_infection_ages])
+    total = 0
+    n = len(imported_infection_ages)
+    if n > _eng.MAX_IMPORT_CLASSES:
+        raise ValueError('too many import age classes')
+    d.n_import_classes = n
+    for k, (age, weight) in enumerate(imported_infection_ages):
+        weight = weight / wsum
+        d.import_class_min_age[k] = int(age)
+        nxt = imported_infection_ages[k + 1][0] if k + 1 < n else nr_ages
+        d.import_class_max_age[k] = min(int(nxt) - 1, nr_ages - 1)
+        d.import_class_cum[k] = float(np.float32(weight + total))
+        total += weight
+    return d, names
+
+
+def pack_contact_tables(tables, nr_ages):
+    """ContactTables (contacts.py) -> the fixed-shape arrays of reina_contact_tables_t."""
+    E = _eng.MAX_ENTRIES
+    nrc = np.zeros(_eng.MAX_AGES, dtype=np.float32)
+    nrc[:nr_ages] = tables.nr_contacts_by_age.astype(np.float32)
+    count = np.zeros(_eng.MAX_AGES, dtype=np.int32)
+    thr = np.full((_eng.MAX_AGES, E), 0xFFFFFFFF, dtype=np.uint32)
+    meta = np.zeros((_eng.MAX_AGES, E), dtype=np.uint32)
+    for a in range(nr_ages):
+        o, c = int(tables.offset[a]), int(tables.count[a])
+        if c > E:
+            raise ValueError('more than %d contact entries for age %d' % (E, a))
+        count[a] = c
+        cum = tables.cum_p[o:o + c]
+        with np.errstate(invalid='ignore'):
+            t = np.floor(np.nan_to_num(cum, nan=0.0) * 4294967296.0)
+        thr[a, :c] = np.clip(t, 0, 4294967295.0).astype(np.uint64).astype(np.uint32)
+        meta[a, :c] = (tables.place[o:o + c].astype(np.uint32)
+                       | (tables.cmin[o:o + c].astype(np.uint32) << 8)
+                       | (tables.cmax[o:o + c].astype(np.uint32) << 16))
+    return nrc, count, thr, meta
+
+
+class Context:
+    """MI355X-native agent engine with the reference `Context` protocol (main.pyx:1746-2101)."""
+
+    def __init__(self, population_params, healthcare_params, disease_params, start_date,
+                 random_seed=4321, device='cuda:0', engine_factory=None):
+        population_params = dict(population_params)
+        ipc = population_params.pop('initial_population_condition', None)
+        if ipc is not None and hasattr(ipc, 'has_initial_state') and ipc.has_initial_state():
+            raise NotImplementedError('set_initial_state (main.pyx:1452-1516) is not supported yet')
+
+        ages = population_params['age_structure']
+        if hasattr(ages, 'items') and hasattr(ages, 'index'):
+            nr_ages = int(ages.index.max()) + 1
+            age_counts = np.zeros(nr_ages, dtype=np.int64)
+            for a, c in ages.items():
+                age_counts[int(a)] = int(c)
+        else:
+            age_counts = np.asarray(ages, dtype=np.int64).copy()
+            nr_ages = len(age_counts)
+        if nr_ages > _eng.MAX_AGES:
+            raise ValueError('at most %d ages' % _eng.MAX_AGES)
+        total = int(age_counts.sum())
+        if total >= 2 ** 31:
+            raise ValueError('a single engine instance holds < 2^31 agents; shard the population')
+        self.nr_ages = nr_ages
+        self.total_people = total
+        self.age_counts = age_counts
+        self.age_start = np.zeros(_eng.MAX_AGES + 1, dtype=np.int64)
+        self.age_start[1:nr_ages + 1] = np.cumsum(age_counts)
+        self.age_start[nr_ages + 1:] = total
+
+        self.age_group_labels = list(population_params['age_groups']['labels'])
+        self.age_group_indices = np.asarray(population_params['age_groups']['age_indices'], dtype=np.int64)
+
+        disease, self.variant_names = build_disease_struct(
+            disease_params, nr_ages, population_params['imported_infection_ages'])
+        self.nr_variants = len(self.variant_names)
+
+        cfg = _eng.Config()
+        cfg.n_agents = total
+        cfg.nr_ages = nr_ages
+        cfg.nr_variants = self.nr_variants
+        cfg.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.max_work_items = total + 64
+        cfg.max_candidates = total + 64
+        cfg.max_queue = total + 64
+        for a in range(_eng.MAX_AGES + 1):
+            cfg.age_start[a] = int(self.age_start[a])
+        if engine_factory is None:
+            self.engine = _eng.hip_engine(cfg, disease, device)
+        else:
+            self.engine = engine_factory(cfg, disease)
+        self.beds = int(healthcare_params['hospital_beds'])
+        self.icu_units = int(healthcare_params['icu_units'])
+        self.engine.init_state(self.beds, self.icu_units)
+
+        self.contact_matrix = ContactMatrix(population_params['contacts_per_day'], nr_ages)
+        self._upload_tables()
+
+        # HealthcareSystem host-side settings (main.pyx:461-472)
+        self.testing_mode = NO_TESTING
+        self.p_detected_anyway = np.float32(0)
+        self.p_successful_tracing = np.float32(1.0)
+        self.vaccinations = []  # dicts(min_age, max_age, nr_daily, slot)
+        # Population weekly imports (main.pyx:1366-1369)
+        self.weekly_infections_amount = 0
+        self.weekly_infections_leftover = [0.0] * (self.nr_variants + 1)
+        self.weekly_infections_shares = [0.0] * self.nr_variants
+        self.weekly_infections_shares[0] = 1.0
+
+        self.start_date = start_date
+        self.day = 0
+        self.interventions = []
+        self._pending_imports = []
+        self._pending_beds = 0
+        self._pending_icu = 0
+        self._keep = []
+
+    # ------------------------------------------------------------------ host helpers
+    def _upload_tables(self):
+        t = self.contact_matrix.tables
+        nrc, count, thr, meta = pack_contact_tables(t, self.nr_ages)
+        mask = np.zeros((_eng.MAX_AGES, 8), dtype=np.float32)
+        mask[:self.nr_ages, :6] = self.contact_matrix.mask_probabilities.astype(np.float32)
+        self.engine.upload_contact_tables(nrc, count, thr, meta, mask)
+
+    def get_date_for_today(self):
+        d = date.fromisoformat(self.start_date)
+        return (d + timedelta(days=self.day)).isoformat()
+
+    def add_intervention(self, iv):
+        self.interventions.append(iv)
+
+    def find_variant(self, variant_str):
+        if variant_str is None:
+            return 0
+        for idx, vn in enumerate(self.variant_names):
+            if variant_str == vn:
+                return idx
+        raise Exception('Variant %s not found' % variant_str)
+
+    # main.pyx:1880-1960
+    def apply_intervention(self, iv):
+        params = iv.get_param_values()
+        t = iv.type
+        if t == 'test-all-with-symptoms':
+            self.testing_mode = ALL_WITH_SYMPTOMS
+        elif t == 'test-only-severe-symptoms':
+            self.testing_mode = ONLY_SEVERE_SYMPTOMS
+            self.p_detected_anyway = np.float32(params['mild_detection_rate'] / 100.0)
+        elif t == 'test-with-contact-tracing':
+            self.testing_mode = ALL_WITH_SYMPTOMS_CT
+            self.p_successful_tracing = np.float32(params['efficiency'] / 100.0)
+        elif t == 'build-new-icu-units':
+            self._pending_icu += int(params['units'])
+        elif t == 'build-new-hospital-beds':
+            self._pending_beds += int(params['beds'])
+        elif t == 'import-infections':
+            self._pending_imports.append((int(params['amount']), self.find_variant(params.get('variant')), 1))
+        elif t == 'import-infections-weekly':
+            shares = [0] * len(self.variant_names)
+            for pn in params.keys():
+                if not pn.startswith('variant_'):
+                    continue
+                vid = self.find_variant(pn.replace('variant_', ''))
+                share = params[pn]
+                shares[vid] = share / 100 if share else 0
+            shares[0] = 1 - sum(shares)
+            self.weekly_infections_amount = int(params['weekly_amount'])
+            self.weekly_infections_shares = shares
+        elif t == 'limit-mobility':
+            reduction = (100 - params['reduction']) / 100.0
+            place = params.get('place')
+            if place is not None:
+                place = PLACES.index(place)
+            self.contact_matrix.set_mobility_factor(reduction, place=place, min_age=params.get('min_age'),
+                                                    max_age=params.get('max_age'))
+        elif t == 'wear-masks':
+            p = params['share_of_contacts'] / 100.0
+            place = params.get('place')
+            if place is not None:
+                place = PLACES.index(place)
+            self.contact_matrix.set_mask_probability(p, place=place, min_age=params.get('min_age'),
+                                                     max_age=params.get('max_age'))
+        elif t == 'vaccinate':
+            nr = params['weekly_vaccinations'] / 7
+            mn, mx = params.get('min_age'), params.get('max_age')
+            for v in self.vaccinations:
+                if v['min_age'] == mn and v['max_age'] == mx:
+                    break
+            else:
+                if len(self.vaccinations) >= _eng.MAX_VACCINATIONS:
+                    raise Exception('too many vaccination programmes')
+                v = dict(min_age=mn, max_age=mx, slot=len(self.vaccinations))
+                self.vaccinations.append(v)
+            v['nr_daily'] = nr
+        else:
+            raise Exception()
+
+    def _build_day(self, history_ptr=None):
+        """Host part of iterate(): interventions dated today, init_day bookkeeping -> reina_day_t.
+        Returns (Day, tables_changed)."""
+        today = self.get_date_for_today()
+        for iv in self.interventions:
+            if iv.date == today:
+                self.apply_intervention(iv)
+        changed = self.contact_matrix.init_day()
+        # Population.infect_people_daily (main.pyx:1671-1685): float32 leftover arithmetic
+        weekly = []
+        for vid in range(self.nr_variants):
+            leftover = np.float32(self.weekly_infections_leftover[vid])
+            leftover = np.float32(float(leftover) + self.weekly_infections_amount / 7.0 * self.weekly_infections_shares[vid])
+            amount_today = int(leftover)
+            if amount_today:
+                weekly.append((amount_today, vid, 0))
+                leftover = np.float32(leftover - np.float32(amount_today))
+            assert leftover >= 0
+            self.weekly_infections_leftover[vid] = float(leftover)
+        d = _eng.Day()
+        d.day = self.day
+        d.testing_mode = self.testing_mode
+        d.p_detected_anyway = float(self.p_detected_anyway)
+        d.p_successful_tracing = float(self.p_successful_tracing)
+        d.add_beds = self._pending_beds
+        d.add_icu_units = self._pending_icu
+        self.beds += self._pending_beds
+        self.icu_units += self._pending_icu
+        self._pending_beds = 0
+        self._pending_icu = 0
+        batches = self._pending_imports + weekly
+        self._pending_imports = []
+        if len(batches) > _eng.MAX_IMPORT_BATCHES:
+            raise Exception('more than %d import batches in one day' % _eng.MAX_IMPORT_BATCHES)
+        d.n_import_batches = len(batches)
+        for k, (count, variant, pre) in enumerate(batches):
+            d.import_batches[k].count = count
+            d.import_batches[k].variant = variant
+            d.import_batches[k].pre_init = pre
+        nv = 0
+        pop_max_age = self.nr_ages - 1
+        for v in self.vaccinations:
+            if not v['nr_daily']:
+                continue
+            mn = 0 if v['min_age'] is None else v['min_age']
+            mx = pop_max_age if v['max_age'] is None else v['max_age']
+            d.vaccinations[nv].nr = int(v['nr_daily'])
+            d.vaccinations[nv].idx_start = int(self.age_start[mn])
+            d.vaccinations[nv].idx_end = int(self.age_start[mx + 1]) if mx < pop_max_age else self.total_people
+            d.vaccinations[nv].slot = v['slot']
+            nv += 1
+        d.n_vaccinations = nv
+        d.history_row = history_ptr
+        return d, changed
+
+    # ------------------------------------------------------------------ day stepping
+    # main.pyx:2011-2018
+    def iterate(self):
+        d, changed = self._build_day()
+        if changed:
+            self._upload_tables()
+        self.engine.step_day(d)
+        self.day += 1
+
+    def run(self, days, record_history=True):
+        """Run `days` consecutive days with one library call per stretch of unchanged contact
+        tables (the loop of calc/simulation.py:194-270 without per-day host round trips).
+        Returns history[days, COUNTER_WORDS] (row d = counters BEFORE day d ran) as a host array,
+        or None; `self.mobility_history[d]` is the mobility factor generate_state() would have
+        reported on that day."""
+        a = self.engine.alloc
+        hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None
+        base = a.ptr(hist) if record_history else 0
+        pending = []
+        self.mobility_history = []
+        for k in range(days):
+            ptr = base + 4 * _eng.COUNTER_WORDS * k if record_history else None
+            self.mobility_history.append(float(self.contact_matrix.mobility_factor))
+            d, changed = self._build_day(ptr)
+            if changed:
+                if pending:
+                    self.engine.run_days(pending)
+                    pending = []
+                self._upload_tables()
+            pending.append(d)
+            self.day += 1
+        if pending:
+            self.engine.run_days(pending)
+        if record_history:
+            out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
+            self._raise_on_problem(self.engine.read_counters())
+            return out
+        return None
+
+    def synchronize(self):
+        self._raise_on_problem(self.engine.read_counters())
+
+    def _raise_on_problem(self, counters):
+        problem = int(counters[_eng.C_NR * _eng.MAX_AGES + _eng.S_PROBLEM])
+        if problem != 0:
+            raise SimulationFailed(PROBLEM_TO_STR.get(problem, 'Problem %d' % problem))
+
+    # ------------------------------------------------------------------ state export
+    def state_from_counters(self, counters, mobility_factor=None):
+        """Context.generate_state (main.pyx:1813-1857) from one counter block."""
+        A = _eng.MAX_AGES
+        sc = counters[_eng.C_NR * A:]
+        total_infections, total_infectors = int(sc[_eng.S_TOTAL_INFECTIONS]), int(sc[_eng.S_TOTAL_INFECTORS])
+        r = total_infections / total_infectors if total_infectors > 5 else 0
+        mf = self.contact_matrix.mobility_factor if mobility_factor is None else mobility_factor
+        s = dict(
+            available_icu_units=int(sc[_eng.S_AVAILABLE_ICU]),
+            available_hospital_beds=int(sc[_eng.S_AVAILABLE_BEDS]),
+            total_icu_units=int(sc[_eng.S_ICU_UNITS]),
+            r=r,
+            exposed_per_day=int(sc[_eng.S_EXPOSED_PER_DAY]),
+            ct_cases_per_day=int(sc[_eng.S_CT_CASES_PER_DAY]),
+            mobility_limitation=1 - float(mf),
+        )
+        ngroups = len(self.age_group_labels)
+        for attr in POP_ATTRS:
+            ci = _eng.C_NAMES.index(attr)
+            per_age = counters[ci * A: ci * A + self.nr_ages]
+            s[attr] = np.bincount(self.age_group_indices[:self.nr_ages], weights=per_age,
+                                  minlength=ngroups).astype(np.int32)
+        s['infected_by_variant'] = {self.variant_names[i]: int(sc[_eng.S_INFECTED_BY_VARIANT + i])
+                                    for i in range(self.nr_variants)}
+        s['daily_contacts'] = {PLACES[i]: int(sc[_eng.S_DAILY_CONTACTS + i]) for i in range(6)}
+        return s
+
+    def generate_state(self):
+        counters = self.engine.read_counters()
+        self._raise_on_problem(counters)
+        return self.state_from_counters(counters)
+
+    # main.pyx:1859-1866
+    def get_population_stats(self, what):
+        if what not in ('dead', 'all_infected', 'all_detected'):
+            raise Exception()
+        counters = self.engine.read_counters()
+        ci = _eng.C_NAMES.index(what)
+        return counters[ci * _eng.MAX_AGES: ci * _eng.MAX_AGES + self.nr_ages].copy()
+
+    def per_age_counters(self):
+        counters = self.engine.read_counters()
+        return {n: counters[i * _eng.MAX_AGES: i * _eng.MAX_AGES + self.nr_ages].copy()
+                for i, n in enumerate(_eng.C_NAMES)}
