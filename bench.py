@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-days/s of the MI355X-native day step, with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--agents A] [--no-cpu] [--no-large]
+
+A "step" is one simulated day (Context.iterate of the reference, cythonsim/main.pyx:2011-2018)
+over the whole population.  At N=1 the workload is BASELINE.json configs[1]: the HUS population
+(1 685 983 agents, real age structure + FI contact matrix), default scenario, K=365 days.
+W warm-up days are simulated first (untimed), then exactly K days are timed between
+barrier + torch.cuda.synchronize() pairs; rank 0 prints ONE JSON line.
+
+Inputs are resident in HBM when the timed region starts (state tensors, tables); per-day host
+work inside the region is the intervention schedule -> day descriptors (+ a 100 KB table upload
+on the 11 days the mobility factors change), exactly what the reference's iterate() does on host.
+
+Extra objects on the line:
+  roofline     dominant kernel k_scan: algorithmic bytes per launch (4 B hot word read per agent +
+               4 B written back per infected agent) / mean launch duration
+               from HIP events recorded on the launch stream inside the timed region, vs 8 TB/s.
+  cpu_baseline the sequential C oracle (oracle/reina_seq.c, bit-exact vs the reference cythonsim)
+               timed on one host core on a bounded sample (first days of the same workload).
+  large        the same measurement on BASELINE configs[2] (synthetic 50 M agents, HUS age shape,
+               beds/ICU/imports scaled) -- the HBM-resident regime the roofline is meant for.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def scaled_scenario(variables, total_agents):
+    """BASELINE configs[2]/[3]: HUS age shape scaled to `total_agents`; beds, ICU
+    units and every import amount scaled by the same factor so prevalence stays comparable."""
+    from reina_model_amd import datasets
+    base = datasets.get_population_for_area()
+    S = total_agents / float(base.sum())
+    v = copy.deepcopy(variables)
+    v['hospital_beds'] = int(round(v['hospital_beds'] * S))
+    v['icu_units'] = int(round(v['icu_units'] * S))
+    ivs = []
+    for iv in v['interventions']:
+        iv = list(iv)
+        if iv[0] in ('import-infections', 'import-infections-weekly'):
+            iv[2] = int(round(iv[2] * S))
+        ivs.append(iv)
+    v['interventions'] = ivs
+    return v, datasets.scaled_population(total_agents)
+
+
+def run_gpu(variables, ages, seed, steps, warmup, device, dist=None):
+    import numpy as np
+    import torch
+    from reina_model_amd import engine as eng
+    from reina_model_amd import simulation
+    ctx = simulation.make_context(variables, age_counts=ages, seed=seed, device=device)
+    if warmup:
+        ctx.run(warmup, record_history=False)
+    ctx.synchronize()
+    ctx.engine.profile_enable(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hist = ctx.run(steps, record_history=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    prof = ctx.engine.profile_read()
+    ctx.engine.profile_enable(False)
+    A = eng.MAX_AGES
+    inf = hist[:, eng.C_NAMES.index('infected') * A:(eng.C_NAMES.index('infected') + 1) * A].sum(axis=1)
+    sc = hist[:, eng.C_NR * A:]
+    stats = dict(
+        mean_infected=float(inf.mean()),
+        contacts=float(sc[:, eng.S_EXPOSED_PER_DAY].sum()),
+        new_infections=float(hist[:, eng.C_NAMES.index('new_infections') * A:(eng.C_NAMES.index('new_infections') + 1) * A].sum()),
+        final_all_infected=int(hist[-1, eng.C_NAMES.index('all_infected') * A:(eng.C_NAMES.index('all_infected') + 1) * A].sum()),
+    )
+    return t1 - t0, prof, stats, int(np.asarray(ages).sum())
+
+
+def roofline_obj(n_agents, steps, prof, stats):
+    # algorithmic bytes of one k_scan launch: every agent's 4-byte hot word read once, the hot
+    # word of every infected agent written back (the 4*N + 4*N_inf terms)
+    bytes_per_launch = 4.0 * n_agents + 4.0 * stats['mean_infected']
+    launches = max(1, int(prof['scan_launches']))
+    ms = prof['scan_ms_total'] / launches
+    achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return dict(bound='hbm', kernel='k_scan', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                bytes_per_launch=bytes_per_launch, avg_launch_ms=round(ms, 6), launches=launches,
+                day_algorithmic_bytes=round((4.0 * n_agents * steps + 4.0 * stats['mean_infected'] * steps
+                                             + 4.0 * stats['contacts'] + 12.0 * stats['new_infections']) / steps, 1),
+                all_kernels_ms_per_day=round(prof['all_ms_total'] / steps, 6))
+
+
+def cpu_baseline(variables, ages, seed, days):
+    from oracle import seq_oracle
+    import numpy as np
+    ctx = seq_oracle.make_context(variables, ages, seed)
+    t0 = time.perf_counter()
+    for _ in range(days):
+        ctx.iterate()
+    dt = time.perf_counter() - t0
+    n = int(np.asarray(ages).sum())
+    return dict(value=round(n * days / dt, 1), unit='agent-days/s', cores=1, kind='port',
+                sample='sequential C restatement of cythonsim (bit-exact vs reference goldens), '
+                       'HUS %d agents, first %d days of the default scenario, 1 thread, %.1f s' % (n, days, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=365)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--agents', type=int, default=0, help='synthetic population per GPU (0 = HUS)')
+    ap.add_argument('--large-agents', type=int, default=50_000_000)
+    ap.add_argument('--cpu-days', type=int, default=120)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-large', action='store_true')
+    ap.add_argument('--seed', type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    device = 'cuda:%d' % local_rank
+
+    from reina_model_amd import datasets
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    if a.agents:
+        v, ages = scaled_scenario(v, a.agents)
+        workload = 'synthetic %d agents/GPU (HUS age structure + FI contact matrix, beds/ICU/imports scaled), default scenario, %d days' % (a.agents, a.steps)
+    else:
+        ages = datasets.get_population_for_area()
+        workload = 'HUS 1685983 agents/GPU, default scenario (variables.py:227-435), %d days' % a.steps
+
+    dt, prof, stats, n_agents = run_gpu(v, ages, a.seed + rank, a.steps, a.warmup, device, dist)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_agents = n_agents * world
+    value = total_agents * a.steps / dt
+
+    out = None
+    if rank == 0:
+        out = {
+            'metric': 'agent-days/sec', 'value': round(value, 1), 'unit': 'agent-days/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt * 1000 / a.steps, 6), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
+            'config': {'workload': workload, 'agents_total': total_agents,
+                       'parallelism': 'single GPU' if world == 1 else 'independent shards x%d (no data-path collective yet)' % world,
+                       'final_all_infected': stats['final_all_infected']},
+            'roofline': roofline_obj(n_agents, a.steps, prof, stats),
+        }
+        traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(traffic_file):
+            try:
+                tj = json.load(open(traffic_file))
+                key = 'hus' if not a.agents else str(a.agents)
+                if key in tj:
+                    out['roofline']['traffic'] = tj[key]
+            except Exception:
+                pass
+        if not a.no_large and world == 1 and not a.agents:
+            vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.large_agents)
+            dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device)
+            out['large'] = {
+                'workload': 'synthetic %d agents (BASELINE configs[2]), default scenario scaled, %d days' % (nl, a.steps),
+                'value': round(nl * a.steps / dtl, 1), 'unit': 'agent-days/s',
+                'ms_per_step': round(dtl * 1000 / a.steps, 6),
+                'roofline': roofline_obj(nl, a.steps, profl, statsl),
+                'final_all_infected': statsl['final_all_infected'],
+            }
+        if not a.no_cpu:
+            hus = datasets.get_population_for_area()
+            out['cpu_baseline'] = cpu_baseline(copy.deepcopy(VARIABLE_DEFAULTS), hus, a.seed, a.cpu_days)
+            out['cpu_baseline']['cores_available'] = os.cpu_count()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -263,6 +263,10 @@ def load_hip_library():
     __graft_entry__.build / reina_model_amd/build.py)."""
     global _hip_lib
     if _hip_lib is None:
+        # PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch first
+        # so the process has ONE HIP runtime: our library's DT_NEEDED libamdhip64.so.7 then binds
+        # to the copy torch already loaded (two runtimes in one process cannot both open the GPU).
+        import torch  # noqa: F401
         if not os.path.exists(HIP_LIB_PATH):
             raise EngineError('HIP extension missing: %s (run `python -m reina_model_amd.build`); '
                               'there is no CPU fallback' % HIP_LIB_PATH)
@@ -271,4 +275,5 @@ def load_hip_library():
 
 
 def hip_engine(config, disease, device='cuda:0'):
-    return Engine(load_hip_library(), 'reina_', TorchAllocator(device), config, disease)
+    alloc = TorchAllocator(device)
+    return Engine(load_hip_library(), 'reina_', alloc, config, disease)
