@@ -30,6 +30,7 @@ extern "C" {
 #define REINA_MAX_IMPORT_BATCHES 16
 #define REINA_MAX_VACCINATIONS 16
 #define REINA_MAX_HOSP_EVENTS 16384
+#define REINA_MAX_SCAN_WAVES 8192
 
 /* error codes */
 #define REINA_OK 0
@@ -147,12 +148,18 @@ typedef struct {
     uint64_t *claim;          /* [N] winner-selection keys, init 0xFF..FF */
     int32_t *counters;        /* [REINA_COUNTER_WORDS] */
     int32_t *control;         /* [REINA_L_NR] */
-    uint32_t *work_items;     /* [max_work_items * 4] (src, nr | variant << 8 | age << 16, src_inf bits, pad) */
-    uint32_t *candidates;     /* [max_candidates * 4] (target, src, variant, prio) */
+    uint32_t *work_items;     /* [max_work_items * 4] (src, nr | variant << 8 | age << 16, src_inf bits, pad);
+                                 max_work_items >= n_agents + 1024 */
+    uint32_t *candidates;     /* [max_candidates * 4] (target, src, variant, prio); target 0xFFFFFFFF = hole */
     uint32_t *queue0;         /* [max_queue] testing queue, even days */
     uint32_t *queue1;         /* [max_queue] testing queue, odd days */
     uint32_t *level1;         /* [max_queue] contact-tracing level-1 work list */
     uint64_t *hosp_events;    /* [REINA_MAX_HOSP_EVENTS] */
+    uint32_t *work_counts;    /* [REINA_MAX_SCAN_WAVES] work items written by each scanning wave into
+                                 its private slice of work_items (no global append counter) */
+    uint32_t *sus_bits;       /* [ceil(N/32)] bit i set <=> agent i is SUSCEPTIBLE (never infected):
+                                 the only thing a sampled contact needs to know about its target
+                                 (person_expose, main.pyx:239), 1 bit instead of a 64-byte struct */
 } reina_buffers_t;
 
 /* `pre_init` = 1 for batches that come from an `import-infections` intervention: the reference

@@ -96,6 +96,8 @@ int par_init_state(Par *e, int32_t beds, int32_t icu, void *stream) {
         e->buf.next_sibling[i] = -1;
         e->buf.claim[i] = ~0ull;
     }
+    for (uint32_t k = 0; k < (N + 31) / 32 + 1; k++) e->buf.sus_bits[k] = 0;
+    for (uint32_t i = 0; i < N; i++) e->buf.sus_bits[i >> 5] |= 1u << (i & 31);
     memset(e->buf.counters, 0, sizeof(int32_t) * REINA_COUNTER_WORDS);
     memset(e->buf.control, 0, sizeof(int32_t) * REINA_L_NR);
     for (uint32_t a = 0; a < e->cfg.nr_ages; a++)
@@ -173,6 +175,7 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
                   (fresh ? RH_FRESH : 0) | (w & RH_VACCINATED) |
                   (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0) | (dl << 16);
     e->buf.hot[t] = nw;
+    e->buf.sus_bits[t >> 5] &= ~(1u << (t & 31));
     if (src >= 0) {
         e->buf.infector[t] = src;
         int old = e->buf.n_infected[src]++;
@@ -339,7 +342,6 @@ static void run_testing(Par *e, const reina_day_t *dp) {
                     if (try_queue(e, (uint32_t)c, i, dp)) queue_append(e, nxt, (uint32_t)c);
         }
     }
-    CTL(e, lcur) = 0;
 }
 
 /* HealthcareSystem.vaccinate_people (main.pyx:560-583): oldest first, persistent cursor (agents
@@ -617,7 +619,7 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
             CTL(e, REINA_L_CONTACTS) += 1;
             if (end <= start) continue;
             uint32_t t = start + r.v[1] % (end - start);
-            if (RH_STATE(e->buf.hot[t]) != RS_SUSCEPTIBLE) continue;
+            if (!((e->buf.sus_bits[t >> 5] >> (t & 31)) & 1u)) continue;
             int age_t = age_of(e, t);
             float p = src_inf * d->p_susceptibility[v][age_t] * d->infectiousness_multiplier[v];
             if (!rp_chance(p, r.v[2])) continue;
@@ -658,6 +660,9 @@ int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
     if (!e->bound) return REINA_E_NOT_BOUND;
     if (dp->history_row) memcpy(dp->history_row, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
     uint32_t import_base = 0;
+    /* the queue processed yesterday becomes today's append target */
+    CTL(e, ((dp->day & 1) ^ 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0) = 0;
+    SC(e, REINA_S_DAY) = (int32_t)dp->day + 1;
     SC(e, REINA_S_BEDS) += dp->add_beds;
     SC(e, REINA_S_AVAILABLE_BEDS) += dp->add_beds;
     SC(e, REINA_S_ICU_UNITS) += dp->add_icu_units;
@@ -686,8 +691,6 @@ int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
     run_hospital(e, dp);
     run_contacts(e, dp);
     run_install(e, dp);
-    SC(e, REINA_S_DAY) = (int32_t)dp->day + 1;
-    SC(e, REINA_S_QUEUE_LEN) = CTL(e, ((dp->day & 1) ^ 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0);
     return 0;
 }
 

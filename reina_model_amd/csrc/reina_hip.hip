@@ -64,6 +64,7 @@ struct reina_engine {
     DevParams h_params;
     Tables h_tables;
     bool testing_ever = false;
+    int uniform_meta = 0;
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
@@ -160,7 +161,7 @@ __device__ __forceinline__ uint32_t clamp_days(int32_t *counters, int d) {
 // word the caller saw; the CAS makes duplicate winner records install once.
 __device__ bool install_infection(const DevParams *P, const reina_buffers_t &B, uint32_t t, uint32_t expect,
                                   uint32_t day, uint32_t variant, int32_t src, int fresh,
-                                  uint32_t testing_mode) {
+                                  uint32_t testing_mode, int32_t *new_by_age, int32_t *new_by_variant) {
     int age = age_of(P->age_start, t, 0, (int)P->nr_ages - 1);
     rp_u4 r = rp_philox(P->k0, P->k1, t, day, RP_P_INFECT, 0);
     float val = rp_uniform24(r.v[0]);
@@ -174,6 +175,7 @@ __device__ bool install_infection(const DevParams *P, const reina_buffers_t &B, 
                   (fresh ? RH_FRESH : 0u) | (expect & RH_VACCINATED) |
                   (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0u) | (dl << 16);
     if (atomicCAS(&B.hot[t], expect, nw) != expect) return false;
+    atomicAnd(&B.sus_bits[t >> 5], ~(1u << (t & 31u)));
     if (src >= 0) {
         B.infector[t] = src;
         int old = atomicAdd(&B.n_infected[src], 1);
@@ -185,12 +187,31 @@ __device__ bool install_infection(const DevParams *P, const reina_buffers_t &B, 
             }
         }
     }
-    atomicAdd(&B.counters[CNT_IDX(REINA_C_SUSCEPTIBLE, age)], -1);
-    atomicAdd(&B.counters[CNT_IDX(REINA_C_INFECTED, age)], 1);
-    atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_INFECTED, age)], 1);
-    atomicAdd(&B.counters[CNT_IDX(REINA_C_NEW_INFECTIONS, age)], 1);
-    atomicAdd(&B.counters[SC_IDX(REINA_S_INFECTED_BY_VARIANT + variant)], 1);
+    atomicAdd(&new_by_age[age], 1);          // workgroup-local (LDS) histograms,
+    atomicAdd(&new_by_variant[variant], 1);  // flushed once per workgroup by flush_new_infections
     return true;
+}
+
+// Population.infect counters (main.pyx:1576-1582) for a workgroup's worth of new infections
+__device__ void flush_new_infections(const reina_buffers_t &B, int32_t *new_by_age, int32_t *new_by_variant,
+                                     int nthreads) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < REINA_MAX_AGES; k += nthreads) {
+        int32_t v = new_by_age[k];
+        if (v) {
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_SUSCEPTIBLE, k)], -v);
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_INFECTED, k)], v);
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_INFECTED, k)], v);
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_NEW_INFECTIONS, k)], v);
+            new_by_age[k] = 0;
+        }
+    }
+    if (threadIdx.x < REINA_MAX_VARIANTS) {
+        int32_t v = new_by_variant[threadIdx.x];
+        if (v) atomicAdd(&B.counters[SC_IDX(REINA_S_INFECTED_BY_VARIANT + threadIdx.x)], v);
+        new_by_variant[threadIdx.x] = 0;
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,6 +228,14 @@ __global__ void k_init(const DevParams *P, reina_buffers_t B, int32_t beds, int3
         B.first_infectee[i] = -1;
         B.next_sibling[i] = -1;
         B.claim[i] = ~0ull;
+    }
+    const uint32_t nwords = (N + 31u) / 32u + 1u;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nwords; k += stride) {
+        uint32_t lo = k * 32u;
+        uint32_t bits = 0;
+        if (lo + 32u <= N) bits = 0xFFFFFFFFu;
+        else if (lo < N) bits = (1u << (N - lo)) - 1u;
+        B.sus_bits[k] = bits;
     }
     if (blockIdx.x == 0) {
         for (uint32_t k = threadIdx.x; k < REINA_COUNTER_WORDS; k += blockDim.x) {
@@ -233,7 +262,8 @@ __global__ void k_init(const DevParams *P, reina_buffers_t B, int32_t beds, int3
 // 10 rounds; every unplaced import proposes one target per round; a susceptible target goes to the
 // lowest import number proposing it (atomicMin on the claim word); the rest retry next round.
 __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, int pre_init,
-                            uint32_t *import_base, uint8_t *placed, uint32_t *s_unplaced) {
+                            uint32_t *import_base, uint8_t *placed, uint32_t *s_unplaced,
+                            int32_t *new_by_age, int32_t *new_by_variant) {
     uint32_t total = 0;
     for (uint32_t b = 0; b < dp.n_import_batches; b++)
         if ((int)dp.import_batches[b].pre_init == pre_init) total += dp.import_batches[b].count;
@@ -298,12 +328,15 @@ __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const 
                     }
                 }
                 uint32_t w = ld_hot(&B.hot[t]);
-                install_infection(P, B, t, w, dp.day, variant, -1, 1, dp.testing_mode);
+                install_infection(P, B, t, w, dp.day, variant, -1, 1, dp.testing_mode, new_by_age, new_by_variant);
                 placed[j] = 1;
             }
         }
-        __threadfence();
         __syncthreads();
+        // every import placed? (workgroup-uniform)
+        int left = 0;
+        for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS) left += placed[j] != 1;
+        if (__syncthreads_or(left) == 0) break;
     }
     if (threadIdx.x == 0) *s_unplaced = 0;
     __syncthreads();
@@ -316,7 +349,7 @@ __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const 
         if (*s_unplaced) atomicAdd(&B.counters[SC_IDX(REINA_S_UNABLE_TO_IMPORT)], (int)*s_unplaced);
         *import_base += total;
     }
-    __syncthreads();
+    flush_new_infections(B, new_by_age, new_by_variant, PRO_THREADS);
 }
 
 // HealthcareSystem.vaccinate_people (main.pyx:560-583): oldest first from a persistent cursor.
@@ -377,21 +410,28 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
     __shared__ uint32_t s_unplaced;
     __shared__ int32_t s_scalar;
     __shared__ uint32_t s_import_base;
+    __shared__ int32_t new_by_age[REINA_MAX_AGES];
+    __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
     const int tid = threadIdx.x;
+    if (tid < REINA_MAX_AGES) new_by_age[tid] = 0;
+    if (tid < REINA_MAX_VARIANTS) new_by_variant[tid] = 0;
     // generate_state() is taken BEFORE iterate() (calc/simulation.py:195 vs :270)
     if (dp.history_row)
         for (int k = tid; k < REINA_COUNTER_WORDS; k += PRO_THREADS) dp.history_row[k] = B.counters[k];
+    __syncthreads();
     if (tid == 0) {
         s_import_base = 0;
+        // the queue processed yesterday becomes today's append target
+        B.control[((dp.day & 1) ^ 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] = 0;
+        B.counters[SC_IDX(REINA_S_DAY)] = (int32_t)dp.day + 1;
         B.counters[SC_IDX(REINA_S_BEDS)] += dp.add_beds;
         B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] += dp.add_beds;
         B.counters[SC_IDX(REINA_S_ICU_UNITS)] += dp.add_icu_units;
         B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] += dp.add_icu_units;
     }
     __syncthreads();
-    pro_imports(P, B, dp, 1, &s_import_base, placed, &s_unplaced);
+    pro_imports(P, B, dp, 1, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant);
     // Population.init_day (main.pyx:1687-1699) + Context._iterate zeroing (:1998-2000)
-    __threadfence();
     __syncthreads();
     for (int k = tid; k < (int)P->nr_ages; k += PRO_THREADS) {
         B.counters[CNT_IDX(REINA_C_NEW_INFECTIONS, k)] = 0;
@@ -413,9 +453,8 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
         // HealthcareSystem.iterate: ct_cases_per_day = len(queue) (main.pyx:518-519)
         B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] = B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
     }
-    __threadfence();
     __syncthreads();
-    pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced);
+    pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant);
     // note: vaccination follows the test-queue pass in the reference (main.pyx:547-558); it only
     // reads DETECTED bits, so it is launched from k_vaccinate after the k_test_* kernels.
 }
@@ -440,7 +479,10 @@ __device__ __forceinline__ void queue_append(const DevParams *P, const reina_buf
 }
 
 // Q1: every queued test is positive (quirk Q8): clear QUEUED, set DETECTED
-__global__ void k_test_detect(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(256) void k_test_detect(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    __shared__ int32_t s_det[REINA_MAX_AGES];
+    if (threadIdx.x < REINA_MAX_AGES) s_det[threadIdx.x] = 0;
+    __syncthreads();
     const int cur = dp.day & 1;
     const uint32_t *q = cur ? B.queue1 : B.queue0;
     const int n = B.control[cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
@@ -449,9 +491,12 @@ __global__ void k_test_detect(const DevParams *P, reina_buffers_t B, reina_day_t
         uint32_t w = B.hot[i];
         if (w & RH_DETECTED) set_problem(B.counters, 7 /* WRONG_STATE */);
         B.hot[i] = (w & ~RH_QUEUED) | RH_DETECTED;
-        int age = age_of(P->age_start, i, 0, (int)P->nr_ages - 1);
-        atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, age)], 1);
-        atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, age)], 1);
+        atomicAdd(&s_det[age_of(P->age_start, i, 0, (int)P->nr_ages - 1)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < REINA_MAX_AGES && s_det[threadIdx.x]) {
+        atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
+        atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
     }
 }
 
@@ -497,158 +542,251 @@ __global__ void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t 
     }
 }
 
-// the processed queue is emptied once both tracing levels are done
-__global__ void k_test_finish(reina_buffers_t B, reina_day_t dp) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] = 0;
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_scan: Context._process_person + person_advance for every agent (main.pyx:1968-1992,395-438)
+//
+// Streaming lanes: each lane loads 16 B (4 hot words) and runs the cheap integer part of the state
+// machine in place (countdown, recover / die at home) and stores changed words back next to where
+// it loaded them.  Everything expensive is compacted with wave ballots into wave-private LDS
+// queues and executed 64 at a time with every lane busy:
+//   expose queue : infectious, undetected agents -> Philox + lognormal contact COUNT -> work item
+//   onset queue  : incubation ran out -> gamma draw of the illness course, testing decision
+//   event queue  : bed / ICU requests and releases -> priority-keyed event for k_hospital
 #define SCAN_THREADS 256
+#define SCAN_WAVES (SCAN_THREADS / 64)
+#define SCAN_QCAP 128
 enum { SL_INFECTED = 0, SL_RECOVERED, SL_DEAD, SL_NHD, SL_NR };
 
 struct ScanShared {
     int32_t age_start[REINA_MAX_AGES + 1];
+    float iot[REINA_MAX_VARIANTS][REINA_IOT_LEN + 3];
     int32_t cnt[SL_NR][REINA_MAX_AGES];
     int32_t total_infectors, total_infections, exposed;
+    uint2 q_exp[SCAN_WAVES][SCAN_QCAP];   // (agent, hot word at start of day)
+    uint2 q_ill[SCAN_WAVES][SCAN_QCAP];   // (agent, hot word after the countdown)
+    uint2 q_ev[SCAN_WAVES][SCAN_QCAP];    // (agent, event type)
 };
 
-__device__ __forceinline__ void emit_event(const DevParams *P, const reina_buffers_t &B, uint32_t i, uint32_t day, int type) {
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// person_become_ill (main.pyx:284-291, 989-1014) + seek_testing (:595-615); `w` already carries
+// days_left == 0 from the countdown
+__device__ void become_ill(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, uint32_t i, uint32_t w) {
+    const reina_disease_t &d = P->dis;
+    int v = RH_VARIANT(w), sev = RH_SEV(w);
+    float mu = sev == RV_FATAL ? d.mean_duration_from_onset_to_death[v] : d.mean_duration_from_onset_to_recovery[v];
+    float od = rp_gamma_mu_cv(mu, 0.45f, P->k0, P->k1, i, dp.day, RP_P_ONSET, 1);
+    B.onset_days[i] = od;
+    float f = od;
+    if (sev >= RV_SEVERE) f *= d.ratio_of_duration_before_hospitalisation[v];
+    w = RH_SET_STATE(w, RS_ILLNESS);
+    w = RH_SET_DAYS_LEFT(w, clamp_days(B.counters, rp_round_to_int(f)));
+    w = RH_SET_DOI(w, 0);
+    if (sev != RV_ASYMPTOMATIC && !(w & RH_DETECTED)) {
+        int q = 0;
+        if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS || dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
+            q = 1;
+        } else if (dp.testing_mode == RT_ONLY_SEVERE_SYMPTOMS) {
+            if (sev >= RV_SEVERE)
+                q = 1;
+            else
+                q = rp_chance(dp.p_detected_anyway, rp_philox(P->k0, P->k1, i, dp.day, RP_P_ONSET, 0).v[3]);
+        }
+        if (q && !(w & RH_QUEUED)) {
+            w |= RH_QUEUED;
+            queue_append(P, B, (dp.day & 1) ^ 1, i);
+        }
+    }
+    B.hot[i] = w;
+}
+
+// person_expose_others -> get_exposed_people -> get_nr_contacts (main.pyx:247-281,936-955,
+// 1308-1320): only the COUNT is drawn here; k_contacts realises the contacts
+__device__ void expose_count(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
+                             bool act, uint32_t i, uint32_t w, uint32_t slice_base, uint32_t &slice_n) {
+    int nr = 0;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (act) {
+        const reina_disease_t &d = P->dis;
+        const uint32_t st = RH_STATE(w);
+        const int v = RH_VARIANT(w), sev = RH_SEV(w);
+        const int dayrel = st == RS_INCUBATION ? -(int)RH_DAYS_LEFT(w) : (int)RH_DOI(w);
+        const float inf = S.iot[v][dayrel + 10];
+        const int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
+        float factor = 1.0f;
+        int limit = 100;
+        if (st == RS_ILLNESS && sev != RV_ASYMPTOMATIC) {
+            factor = 0.5f;
+            limit = 5;
+        }
+        float z = rp_normal_from_u32(rp_philox(P->k0, P->k1, i, dp.day, RP_P_NRCONTACTS, 0).v[0]);
+        float f = rp_expf(0.5f * z) * P->nrc[age];
+        f *= factor;
+        if (f < 1.0f) f = 1.0f;
+        nr = (int)f - 1;
+        if (nr > limit) nr = limit;
+        rec = make_uint4(i, (uint32_t)nr | ((uint32_t)v << 8) | ((uint32_t)age << 16), 0u, 0u);
+        if (nr > 0) {
+            float src_inf = inf;
+            if (sev == RV_ASYMPTOMATIC) src_inf *= d.p_asymptomatic_infection[v];
+            rec.z = rp_f2u(src_inf);
+        }
+    }
+    // work items go to this wave's private slice of the list: a ballot gives the slots, no atomic
+    const uint64_t m = __ballot(nr > 0);
+    if (nr > 0) {
+        uint32_t pos = slice_base + slice_n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        if (pos >= P->max_work_items)
+            set_problem(B.counters, REINA_PROBLEM_WORK_OVERFLOW);
+        else
+            reinterpret_cast<uint4 *>(B.work_items)[pos] = rec;
+    }
+    slice_n += (uint32_t)__popcll(m);
+    int tot = wave_sum(nr);
+    if (tot && lane_id() == 0) atomicAdd(&S.exposed, tot);
+}
+
+__device__ void emit_events(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, bool act, uint32_t i, int type) {
+    if (!act) return;
     uint32_t pos = wave_alloc(&B.control[REINA_L_HOSP]);
     if (pos >= REINA_MAX_HOSP_EVENTS) {
         set_problem(B.counters, REINA_PROBLEM_HOSPITAL_OVERFLOW);
         return;
     }
-    uint64_t prio = rp_priority20(P->k0, P->k1, i, day);
+    uint64_t prio = rp_priority20(P->k0, P->k1, i, dp.day);
     B.hosp_events[pos] = (prio << 34) | ((uint64_t)i << 2) | (uint64_t)type;
     if (type == EV_HOSPITALIZE) atomicAdd(&B.control[REINA_L_HOSP_ADMIT], 1);
     if (type == EV_TO_ICU) atomicAdd(&B.control[REINA_L_ICU_ADMIT], 1);
 }
 
-// one infected (or newly removed) agent
-__device__ void process_agent(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
-                              uint32_t i, uint32_t w) {
-    const reina_disease_t &d = P->dis;
-    uint32_t st = RH_STATE(w);
-    if (st >= RS_RECOVERED) {
-        // R bookkeeping: the first scan that sees a removed agent (main.pyx:1969-1972)
+// wave-private LDS queues: all accesses come from one wave and LDS executes a wave's operations
+// in order, so only the compiler has to be kept from reordering (volatile)
+__device__ __forceinline__ void wq_push(volatile uint2 *q, int &qn, bool pred, uint32_t x, uint32_t y) {
+    uint64_t m = __ballot(pred);
+    if (pred) {
+        int pos = qn + (int)__popcll(m & ((1ull << lane_id()) - 1ull));
+        q[pos].x = x;
+        q[pos].y = y;
+    }
+    qn += (int)__popcll(m);
+}
+// pops up to 64 entries (the newest); returns whether this lane holds one
+__device__ __forceinline__ bool wq_pop64(volatile uint2 *q, int &qn, uint32_t &x, uint32_t &y) {
+    int take = qn < 64 ? qn : 64;
+    int base = qn - take;
+    bool act = lane_id() < take;
+    x = 0;
+    y = 0;
+    if (act) {
+        x = q[base + lane_id()].x;
+        y = q[base + lane_id()].y;
+    }
+    qn = base;
+    return act;
+}
+
+struct ScanQueues {
+    volatile uint2 *exp_, *ill, *ev;
+    int n_exp, n_ill, n_ev;
+    uint32_t slice_base, slice_n;  // this wave's slice of work_items
+};
+
+__device__ __forceinline__ void scan_drain(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
+                                           ScanQueues &Q, int min_fill) {
+    uint32_t x, y;
+    while (Q.n_exp >= min_fill && Q.n_exp > 0) {
+        bool act = wq_pop64(Q.exp_, Q.n_exp, x, y);
+        expose_count(P, B, dp, S, act, x, y, Q.slice_base, Q.slice_n);
+    }
+    while (Q.n_ill >= min_fill && Q.n_ill > 0) {
+        bool act = wq_pop64(Q.ill, Q.n_ill, x, y);
+        if (act) become_ill(P, B, dp, x, y);
+    }
+    while (Q.n_ev >= min_fill && Q.n_ev > 0) {
+        bool act = wq_pop64(Q.ev, Q.n_ev, x, y);
+        emit_events(P, B, dp, act, x, (int)y);
+    }
+}
+
+// the cheap in-place part for one hot word; returns the word to store (or `w` itself when nothing
+// changes or the final word is written later by the onset queue)
+__device__ __forceinline__ uint32_t scan_word(const DevParams *P, const reina_buffers_t &B, ScanShared &S, ScanQueues &Q,
+                                               bool valid, uint32_t i, uint32_t w) {
+    const uint32_t st = RH_STATE(w);
+    bool infected = valid && st >= RS_INCUBATION && st <= RS_IN_ICU;
+    bool p_exp = false, p_ill = false, p_ev = false;
+    uint32_t ev_type = 0, nw = w;
+    if (valid && st >= RS_RECOVERED && !(w & RH_INCLUDED)) {
+        // R bookkeeping: the first scan that sees a removed agent (main.pyx:1969-1972); once per agent
         atomicAdd(&S.total_infectors, 1);
-        atomicAdd(&S.total_infections, B.n_infected[i]);
-        B.hot[i] = w | RH_INCLUDED;
-        return;
+        int ni = B.n_infected[i];
+        if (ni) atomicAdd(&S.total_infections, ni);
+        nw = w | RH_INCLUDED;
     }
-    if (st == RS_INCUBATION && (w & RH_FRESH)) {  // infected earlier today: waits (main.pyx:402)
-        B.hot[i] = w & ~RH_FRESH;
-        return;
-    }
-    int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
-    int v = RH_VARIANT(w), sev = RH_SEV(w);
-    uint32_t dl = RH_DAYS_LEFT(w);
-    if (st == RS_INCUBATION || st == RS_ILLNESS) {
-        // person_expose_others -> get_exposed_people -> get_nr_contacts (main.pyx:247-281,936-955,
-        // 1308-1320): only the COUNT is drawn here; k_contacts realises the contacts
-        int nr = 0;
-        if (!(w & RH_DETECTED)) {
-            int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w);
-            float inf = (dayrel >= -10 && dayrel <= 10) ? d.infectiousness_over_time[v][dayrel + 10] : 0.0f;
-            if (inf != 0.0f) {
-                float factor = 1.0f;
-                int limit = 100;
-                if (st == RS_ILLNESS && sev != RV_ASYMPTOMATIC) {
-                    factor = 0.5f;
-                    limit = 5;
+    if (infected) {
+        if (st == RS_INCUBATION && (w & RH_FRESH)) {  // infected earlier today: waits (main.pyx:402)
+            nw = w & ~RH_FRESH;
+        } else {
+            const int v = RH_VARIANT(w), sev = RH_SEV(w);
+            uint32_t dl = RH_DAYS_LEFT(w);
+            if (st <= RS_ILLNESS) {
+                if (!(w & RH_DETECTED)) {
+                    int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w);
+                    p_exp = dayrel >= -10 && dayrel <= 10 && S.iot[v][dayrel + 10] != 0.0f;
                 }
-                float z = rp_normal_from_u32(rp_philox(P->k0, P->k1, i, dp.day, RP_P_NRCONTACTS, 0).v[0]);
-                float f = rp_expf(0.5f * z) * P->nrc[age];
-                f *= factor;
-                if (f < 1.0f) f = 1.0f;
-                nr = (int)f - 1;
-                if (nr > limit) nr = limit;
-                if (nr > 0) {
-                    float src_inf = inf;
-                    if (sev == RV_ASYMPTOMATIC) src_inf *= d.p_asymptomatic_infection[v];
-                    uint32_t pos = wave_alloc(&B.control[REINA_L_WORK]);
-                    if (pos >= P->max_work_items) {
-                        set_problem(B.counters, REINA_PROBLEM_WORK_OVERFLOW);
-                    } else {
-                        uint4 rec = make_uint4(i, (uint32_t)nr | ((uint32_t)v << 8) | ((uint32_t)age << 16), rp_f2u(src_inf), 0u);
-                        reinterpret_cast<uint4 *>(B.work_items)[pos] = rec;
-                    }
-                }
-            }
-        }
-        if (nr) atomicAdd(&S.exposed, nr);
-        if (st == RS_INCUBATION) {
-            if (dl > 0) dl--;
-            if (dl == 0) {
-                // person_become_ill (main.pyx:284-291, 989-1014) + seek_testing (:595-615)
-                float mu = sev == RV_FATAL ? d.mean_duration_from_onset_to_death[v] : d.mean_duration_from_onset_to_recovery[v];
-                float od = rp_gamma_mu_cv(mu, 0.45f, P->k0, P->k1, i, dp.day, RP_P_ONSET, 1);
-                B.onset_days[i] = od;
-                float f = od;
-                if (sev >= RV_SEVERE) f *= d.ratio_of_duration_before_hospitalisation[v];
-                w = RH_SET_STATE(w, RS_ILLNESS);
-                w = RH_SET_DAYS_LEFT(w, clamp_days(B.counters, rp_round_to_int(f)));
-                w = RH_SET_DOI(w, 0);
-                if (sev != RV_ASYMPTOMATIC && !(w & RH_DETECTED)) {
-                    int q = 0;
-                    if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS || dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-                        q = 1;
-                    } else if (dp.testing_mode == RT_ONLY_SEVERE_SYMPTOMS) {
-                        if (sev >= RV_SEVERE)
-                            q = 1;
-                        else
-                            q = rp_chance(dp.p_detected_anyway, rp_philox(P->k0, P->k1, i, dp.day, RP_P_ONSET, 0).v[3]);
-                    }
-                    if (q && !(w & RH_QUEUED)) {
-                        w |= RH_QUEUED;
-                        queue_append(P, B, (dp.day & 1) ^ 1, i);
+                if (st == RS_INCUBATION) {
+                    if (dl > 0) dl--;
+                    nw = RH_SET_DAYS_LEFT(w, dl);
+                    if (dl == 0) p_ill = true;  // become_ill stores the final word
+                } else {
+                    uint32_t doi = RH_DOI(w);
+                    if (doi < 255) doi++;
+                    if (dl > 0) dl--;
+                    nw = RH_SET_DOI(RH_SET_DAYS_LEFT(w, dl), doi);
+                    if (dl == 0) {
+                        if (sev == RV_FATAL && (w & RH_POD_OUTSIDE)) {
+                            int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
+                            atomicAdd(&S.cnt[SL_INFECTED][age], -1);
+                            atomicAdd(&S.cnt[SL_DEAD][age], 1);
+                            atomicAdd(&S.cnt[SL_NHD][age], 1);
+                            nw = RH_SET_STATE(nw, RS_DEAD) & ~RH_HASLIST;
+                        } else if (sev >= RV_SEVERE) {
+                            p_ev = true;
+                            ev_type = EV_HOSPITALIZE;
+                        } else {
+                            int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
+                            atomicAdd(&S.cnt[SL_INFECTED][age], -1);
+                            atomicAdd(&S.cnt[SL_RECOVERED][age], 1);
+                            nw = RH_SET_STATE(nw, RS_RECOVERED) & ~RH_HASLIST;
+                        }
                     }
                 }
             } else {
-                w = RH_SET_DAYS_LEFT(w, dl);
-            }
-        } else {
-            uint32_t doi = RH_DOI(w);
-            if (doi < 255) doi++;
-            if (dl > 0) dl--;
-            w = RH_SET_DOI(RH_SET_DAYS_LEFT(w, dl), doi);
-            if (dl == 0) {
-                if (sev == RV_FATAL && (w & RH_POD_OUTSIDE)) {
-                    atomicAdd(&S.cnt[SL_INFECTED][age], -1);
-                    atomicAdd(&S.cnt[SL_DEAD][age], 1);
-                    atomicAdd(&S.cnt[SL_NHD][age], 1);
-                    w = RH_SET_STATE(w, RS_DEAD) & ~RH_HASLIST;
-                } else if (sev >= RV_SEVERE) {
-                    emit_event(P, B, i, dp.day, EV_HOSPITALIZE);
-                } else {
-                    atomicAdd(&S.cnt[SL_INFECTED][age], -1);
-                    atomicAdd(&S.cnt[SL_RECOVERED][age], 1);
-                    w = RH_SET_STATE(w, RS_RECOVERED) & ~RH_HASLIST;
+                if (dl > 0) dl--;
+                nw = RH_SET_DAYS_LEFT(w, dl);
+                if (dl == 0) {
+                    p_ev = true;
+                    ev_type = st == RS_HOSPITALIZED ? (sev >= RV_CRITICAL ? EV_TO_ICU : EV_RELEASE_WARD) : EV_RELEASE_ICU;
                 }
             }
         }
-    } else if (st == RS_HOSPITALIZED) {
-        if (dl > 0) dl--;
-        w = RH_SET_DAYS_LEFT(w, dl);
-        if (dl == 0) emit_event(P, B, i, dp.day, sev >= RV_CRITICAL ? EV_TO_ICU : EV_RELEASE_WARD);
-    } else {
-        if (dl > 0) dl--;
-        w = RH_SET_DAYS_LEFT(w, dl);
-        if (dl == 0) emit_event(P, B, i, dp.day, EV_RELEASE_ICU);
     }
-    B.hot[i] = w;
-}
-
-__device__ __forceinline__ bool needs_processing(uint32_t w) {
-    uint32_t st = RH_STATE(w);
-    return st != RS_SUSCEPTIBLE && !(st >= RS_RECOVERED && (w & RH_INCLUDED));
+    wq_push(Q.exp_, Q.n_exp, p_exp, i, w);
+    wq_push(Q.ill, Q.n_ill, p_ill, i, nw);
+    wq_push(Q.ev, Q.n_ev, p_ev, i, ev_type);
+    return p_ill ? w : nw;
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
     __shared__ ScanShared S;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k <= REINA_MAX_AGES; k += SCAN_THREADS) S.age_start[k] = P->age_start[k];
+    for (int k = tid; k < REINA_MAX_VARIANTS * (REINA_IOT_LEN + 3); k += SCAN_THREADS)
+        (&S.iot[0][0])[k] = (&P->dis.infectiousness_over_time[0][0])[k];
     for (int k = tid; k < SL_NR * REINA_MAX_AGES; k += SCAN_THREADS) (&S.cnt[0][0])[k] = 0;
     if (tid == 0) {
         S.total_infectors = 0;
@@ -656,22 +794,70 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
         S.exposed = 0;
     }
     __syncthreads();
+    ScanQueues Q;
+    Q.exp_ = S.q_exp[wave];
+    Q.ill = S.q_ill[wave];
+    Q.ev = S.q_ev[wave];
+    Q.n_exp = Q.n_ill = Q.n_ev = 0;
     const uint32_t N = P->n_agents;
     const uint32_t n4 = N >> 2;
-    const uint4 *hot4 = reinterpret_cast<const uint4 *>(B.hot);
-    const uint32_t stride = gridDim.x * SCAN_THREADS;
-    for (uint32_t q = blockIdx.x * SCAN_THREADS + tid; q < n4; q += stride) {
-        uint4 w4 = hot4[q];
-        if (needs_processing(w4.x)) process_agent(P, B, dp, S, 4 * q + 0, w4.x);
-        if (needs_processing(w4.y)) process_agent(P, B, dp, S, 4 * q + 1, w4.y);
-        if (needs_processing(w4.z)) process_agent(P, B, dp, S, 4 * q + 2, w4.z);
-        if (needs_processing(w4.w)) process_agent(P, B, dp, S, 4 * q + 3, w4.w);
+    uint4 *hot4 = reinterpret_cast<uint4 *>(B.hot);
+    // each wave walks tiles of 128 uint4 (two 1-KiB loads in flight per wave)
+    const uint32_t tiles = (n4 + 127u) / 128u;
+    const uint32_t wave_global = blockIdx.x * SCAN_WAVES + wave, waves_total = gridDim.x * SCAN_WAVES;
+    {   // wave w owns tiles w, w+W, ...; its work items land in a slice as large as the agents it scans
+        const uint32_t tq = tiles / waves_total, tr = tiles % waves_total;
+        Q.slice_base = 512u * (wave_global * tq + (wave_global < tr ? wave_global : tr));
+        Q.slice_n = 0;
     }
-    if (blockIdx.x == 0 && tid < (int)(N & 3u)) {
-        uint32_t i = (n4 << 2) + tid;
-        uint32_t w = B.hot[i];
-        if (needs_processing(w)) process_agent(P, B, dp, S, i, w);
+    for (uint32_t t = wave_global; t < tiles; t += waves_total) {
+        const uint32_t q0 = t * 128u + lane, q1 = q0 + 64u;
+        const bool v0 = q0 < n4, v1 = q1 < n4;
+        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+        if (v0) a = hot4[q0];
+        if (v1) b = hot4[q1];
+        // nothing to do in this tile for the whole wave? (all susceptible / counted)
+        const bool any = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u;
+        if (!__any(any)) continue;
+        uint4 na, nb;
+        na.x = scan_word(P, B, S, Q, v0, 4 * q0 + 0, a.x);
+        scan_drain(P, B, dp, S, Q, 64);
+        na.y = scan_word(P, B, S, Q, v0, 4 * q0 + 1, a.y);
+        scan_drain(P, B, dp, S, Q, 64);
+        na.z = scan_word(P, B, S, Q, v0, 4 * q0 + 2, a.z);
+        scan_drain(P, B, dp, S, Q, 64);
+        na.w = scan_word(P, B, S, Q, v0, 4 * q0 + 3, a.w);
+        scan_drain(P, B, dp, S, Q, 64);
+        nb.x = scan_word(P, B, S, Q, v1, 4 * q1 + 0, b.x);
+        scan_drain(P, B, dp, S, Q, 64);
+        nb.y = scan_word(P, B, S, Q, v1, 4 * q1 + 1, b.y);
+        scan_drain(P, B, dp, S, Q, 64);
+        nb.z = scan_word(P, B, S, Q, v1, 4 * q1 + 2, b.z);
+        scan_drain(P, B, dp, S, Q, 64);
+        nb.w = scan_word(P, B, S, Q, v1, 4 * q1 + 3, b.w);
+        scan_drain(P, B, dp, S, Q, 64);
+        // component stores: a deferred (onset) word keeps its old value here and is written by
+        // become_ill; unchanged words are not written at all
+        uint32_t *h = B.hot;
+        if (na.x != a.x) h[4 * q0 + 0] = na.x;
+        if (na.y != a.y) h[4 * q0 + 1] = na.y;
+        if (na.z != a.z) h[4 * q0 + 2] = na.z;
+        if (na.w != a.w) h[4 * q0 + 3] = na.w;
+        if (nb.x != b.x) h[4 * q1 + 0] = nb.x;
+        if (nb.y != b.y) h[4 * q1 + 1] = nb.y;
+        if (nb.z != b.z) h[4 * q1 + 2] = nb.z;
+        if (nb.w != b.w) h[4 * q1 + 3] = nb.w;
     }
+    if (wave_global == 0) {  // ragged tail: N not a multiple of 4
+        uint32_t i = (n4 << 2) + lane;
+        uint32_t w = 0;
+        bool in = lane < (int)(N & 3u);
+        if (in) w = B.hot[i];
+        uint32_t nw = scan_word(P, B, S, Q, in, i, w);
+        if (in && nw != w) B.hot[i] = nw;
+    }
+    scan_drain(P, B, dp, S, Q, 1);
+    if (lane == 0) B.work_counts[wave_global] = Q.slice_n;
     __syncthreads();
     for (int k = tid; k < SL_NR * REINA_MAX_AGES; k += SCAN_THREADS) {
         int32_t v = (&S.cnt[0][0])[k];
@@ -707,20 +893,61 @@ __device__ __forceinline__ int dies_in_hospital(const DevParams *P, uint32_t i, 
     return rp_chance(p, rp_philox(P->k0, P->k1, i, day, RP_P_HOSPITAL, 0).v[0]);
 }
 
+// saturating-counter walk as a scan: every event acts on the free-bed count x as
+// f(x) = max(x + a, m) (admission: a=-1, m=0; release: a=+1, m=-inf); such maps compose to the
+// same form, (a1,m1) then (a2,m2) = (a1+a2, max(m1+a2, m2)), so "free beds just before event k"
+// is a prefix composition -- computed by a workgroup scan instead of a serial loop.
+struct SatFn { int a, m; };
+#define SAT_NEG (-(1 << 29))
+__device__ __forceinline__ SatFn sat_then(SatFn f, SatFn g) {  // f first, then g
+    SatFn r;
+    r.a = f.a + g.a;
+    int t = f.m + g.a;
+    if (t < SAT_NEG) t = SAT_NEG;
+    r.m = t > g.m ? t : g.m;
+    return r;
+}
+__device__ __forceinline__ int sat_apply(SatFn f, int x) {
+    int y = x + f.a;
+    return y > f.m ? y : f.m;
+}
+__device__ __forceinline__ SatFn bed_fn(int type) {
+    SatFn f;
+    f.m = SAT_NEG;
+    f.a = 0;
+    if (type == EV_HOSPITALIZE) { f.a = -1; f.m = 0; }
+    else if (type == EV_TO_ICU || type == EV_RELEASE_WARD) f.a = 1;
+    return f;
+}
+__device__ __forceinline__ SatFn icu_fn(int type) {
+    SatFn f;
+    f.m = SAT_NEG;
+    f.a = 0;
+    if (type == EV_TO_ICU) { f.a = -1; f.m = 0; }
+    else if (type == EV_RELEASE_ICU) f.a = 1;
+    return f;
+}
+
+enum { HL_INFECTED = 0, HL_DETECTED, HL_ALL_DETECTED, HL_HOSPITALIZED, HL_IN_WARD, HL_IN_ICU, HL_CUM_ICU,
+       HL_DEAD, HL_NHD, HL_RECOVERED, HL_NR };
+
 __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *ev = reinterpret_cast<uint64_t *>(smem);               // [M2]
     __shared__ int s_b, s_c;
+    __shared__ SatFn s_fb[HOSP_THREADS], s_fc[HOSP_THREADS];
+    __shared__ int32_t s_cnt[HL_NR][REINA_MAX_AGES];
     const int tid = threadIdx.x;
     int M = B.control[REINA_L_HOSP];
     if (M > REINA_MAX_HOSP_EVENTS) M = REINA_MAX_HOSP_EVENTS;
     if (M == 0) return;
     int M2 = 1;
     while (M2 < M) M2 <<= 1;
-    uint8_t *flag = smem + sizeof(uint64_t) * M2;                    // [M] success flags
+    // an admission that finds no free bed / ICU unit is marked in bit 63 of its event word
     const int b0 = B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)], c0 = B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)];
     const bool ordered = !(b0 >= B.control[REINA_L_HOSP_ADMIT] && c0 >= B.control[REINA_L_ICU_ADMIT]);
     for (int k = tid; k < M2; k += HOSP_THREADS) ev[k] = k < M ? B.hosp_events[k] : ~0ull;
+    for (int k = tid; k < HL_NR * REINA_MAX_AGES; k += HOSP_THREADS) (&s_cnt[0][0])[k] = 0;
     __syncthreads();
     if (ordered) {
         for (int size = 2; size <= M2; size <<= 1) {
@@ -739,25 +966,57 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
                 __syncthreads();
             }
         }
-        if (tid == 0) {
-            int b = b0, c = c0;
-            for (int k = 0; k < M; k++) {
-                int type = (int)(ev[k] & 3);
-                uint8_t ok = 1;
-                if (type == EV_HOSPITALIZE) {
-                    if (b == 0) ok = 0; else b--;
-                } else if (type == EV_TO_ICU) {
-                    b++;
-                    if (c == 0) ok = 0; else c--;
-                } else if (type == EV_RELEASE_WARD) {
-                    b++;
-                } else {
-                    c++;
-                }
-                flag[k] = ok;
+        // chunked scan: thread t owns events [t*per, (t+1)*per)
+        const int per = (M + HOSP_THREADS - 1) / HOSP_THREADS;
+        const int lo = tid * per, hi = min(M, lo + per);
+        SatFn fb, fc;
+        fb.a = fc.a = 0;
+        fb.m = fc.m = SAT_NEG;
+        for (int k = lo; k < hi; k++) {
+            int type = (int)(ev[k] & 3);
+            fb = sat_then(fb, bed_fn(type));
+            fc = sat_then(fc, icu_fn(type));
+        }
+        s_fb[tid] = fb;
+        s_fc[tid] = fc;
+        __syncthreads();
+        // inclusive Hillis-Steele scan of the per-thread maps (composition is associative)
+        for (int off = 1; off < HOSP_THREADS; off <<= 1) {
+            SatFn pb = fb, pc = fc;
+            if (tid >= off) {
+                pb = sat_then(s_fb[tid - off], fb);
+                pc = sat_then(s_fc[tid - off], fc);
             }
-            s_b = b;
-            s_c = c;
+            __syncthreads();
+            fb = pb;
+            fc = pc;
+            s_fb[tid] = fb;
+            s_fc[tid] = fc;
+            __syncthreads();
+        }
+        int b = b0, c = c0;
+        if (tid > 0) {
+            b = sat_apply(s_fb[tid - 1], b0);
+            c = sat_apply(s_fc[tid - 1], c0);
+        }
+        for (int k = lo; k < hi; k++) {
+            int type = (int)(ev[k] & 3);
+            uint8_t ok = 1;
+            if (type == EV_HOSPITALIZE) {
+                if (b == 0) ok = 0; else b--;
+            } else if (type == EV_TO_ICU) {
+                b++;
+                if (c == 0) ok = 0; else c--;
+            } else if (type == EV_RELEASE_WARD) {
+                b++;
+            } else {
+                c++;
+            }
+            if (!ok) ev[k] |= 1ull << 63;
+        }
+        if (tid == HOSP_THREADS - 1) {
+            s_b = sat_apply(s_fb[HOSP_THREADS - 1], b0);
+            s_c = sat_apply(s_fc[HOSP_THREADS - 1], c0);
         }
     } else {
         if (tid == 0) {
@@ -768,7 +1027,6 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
         int db = 0, dc = 0;
         for (int k = tid; k < M; k += HOSP_THREADS) {
             int type = (int)(ev[k] & 3);
-            flag[k] = 1;
             if (type == EV_HOSPITALIZE) db--;
             else if (type == EV_TO_ICU) { db++; dc--; }
             else if (type == EV_RELEASE_WARD) db++;
@@ -782,6 +1040,7 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
     for (int k = tid; k < M; k += HOSP_THREADS) {
         uint64_t e = ev[k];
         int type = (int)(e & 3);
+        const bool granted = !(e >> 63);
         uint32_t i = (uint32_t)((e >> 2) & 0xFFFFFFFFu);
         uint32_t w = B.hot[i];
         int age = age_of(P->age_start, i, 0, (int)P->nr_ages - 1), v = RH_VARIANT(w), sev = RH_SEV(w);
@@ -790,10 +1049,10 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
         if (type == EV_HOSPITALIZE) {
             if (!(w & RH_DETECTED)) {
                 w |= RH_DETECTED;
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, age)], 1);
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, age)], 1);
+                atomicAdd(&s_cnt[HL_DETECTED][age], 1);
+                atomicAdd(&s_cnt[HL_ALL_DETECTED][age], 1);
             }
-            if (!flag[k]) {
+            if (!granted) {
                 died = dies_in_hospital(P, i, dp.day, sev, v, 0);
             } else {
                 float f;
@@ -802,42 +1061,52 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
                 else
                     f = od * d.ratio_of_duration_in_ward[v];
                 w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(B.counters, rp_round_to_int(f)));
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_HOSPITALIZED, age)], 1);
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_WARD, age)], 1);
+                atomicAdd(&s_cnt[HL_HOSPITALIZED][age], 1);
+                atomicAdd(&s_cnt[HL_IN_WARD][age], 1);
             }
         } else if (type == EV_TO_ICU) {
-            if (!flag[k] && dies_in_hospital(P, i, dp.day, sev, v, 0)) {
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_WARD, age)], -1);
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_HOSPITALIZED, age)], -1);
+            if (!granted && dies_in_hospital(P, i, dp.day, sev, v, 0)) {
+                atomicAdd(&s_cnt[HL_IN_WARD][age], -1);
+                atomicAdd(&s_cnt[HL_HOSPITALIZED][age], -1);
                 died = 1;
             } else {
                 float f = 1.0f - d.ratio_of_duration_in_ward[v] - d.ratio_of_duration_before_hospitalisation[v];
                 f *= od;
                 w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(B.counters, rp_round_to_int(f)));
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_WARD, age)], -1);
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_ICU, age)], 1);
-                atomicAdd(&B.counters[CNT_IDX(REINA_C_CUM_ICU, age)], 1);
+                atomicAdd(&s_cnt[HL_IN_WARD][age], -1);
+                atomicAdd(&s_cnt[HL_IN_ICU][age], 1);
+                atomicAdd(&s_cnt[HL_CUM_ICU][age], 1);
             }
         } else if (type == EV_RELEASE_WARD) {
-            atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_WARD, age)], -1);
-            atomicAdd(&B.counters[CNT_IDX(REINA_C_HOSPITALIZED, age)], -1);
+            atomicAdd(&s_cnt[HL_IN_WARD][age], -1);
+            atomicAdd(&s_cnt[HL_HOSPITALIZED][age], -1);
             died = dies_in_hospital(P, i, dp.day, sev, v, 1);
         } else {
-            atomicAdd(&B.counters[CNT_IDX(REINA_C_IN_ICU, age)], -1);
-            atomicAdd(&B.counters[CNT_IDX(REINA_C_HOSPITALIZED, age)], -1);
+            atomicAdd(&s_cnt[HL_IN_ICU][age], -1);
+            atomicAdd(&s_cnt[HL_HOSPITALIZED][age], -1);
             died = dies_in_hospital(P, i, dp.day, sev, v, 1);
         }
         if (died == 1) {
-            atomicAdd(&B.counters[CNT_IDX(REINA_C_INFECTED, age)], -1);
-            atomicAdd(&B.counters[CNT_IDX(REINA_C_DEAD, age)], 1);
-            if (w & RH_POD_OUTSIDE) atomicAdd(&B.counters[CNT_IDX(REINA_C_NON_HOSPITAL_DEATHS, age)], 1);
+            atomicAdd(&s_cnt[HL_INFECTED][age], -1);
+            atomicAdd(&s_cnt[HL_DEAD][age], 1);
+            if (w & RH_POD_OUTSIDE) atomicAdd(&s_cnt[HL_NHD][age], 1);
             w = RH_SET_STATE(w, RS_DEAD) & ~RH_HASLIST;
         } else if (died == 0) {
-            atomicAdd(&B.counters[CNT_IDX(REINA_C_INFECTED, age)], -1);
-            atomicAdd(&B.counters[CNT_IDX(REINA_C_RECOVERED, age)], 1);
+            atomicAdd(&s_cnt[HL_INFECTED][age], -1);
+            atomicAdd(&s_cnt[HL_RECOVERED][age], 1);
             w = RH_SET_STATE(w, RS_RECOVERED) & ~RH_HASLIST;
         }
         B.hot[i] = w;
+    }
+    __syncthreads();
+    for (int k = tid; k < HL_NR * REINA_MAX_AGES; k += HOSP_THREADS) {
+        int32_t v = (&s_cnt[0][0])[k];
+        if (v) {
+            const int map[HL_NR] = {REINA_C_INFECTED, REINA_C_DETECTED, REINA_C_ALL_DETECTED, REINA_C_HOSPITALIZED,
+                                    REINA_C_IN_WARD, REINA_C_IN_ICU, REINA_C_CUM_ICU, REINA_C_DEAD,
+                                    REINA_C_NON_HOSPITAL_DEATHS, REINA_C_RECOVERED};
+            atomicAdd(&B.counters[CNT_IDX(map[k / REINA_MAX_AGES], k % REINA_MAX_AGES)], v);
+        }
     }
     if (tid == 0) {
         B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] = s_b;
@@ -852,10 +1121,11 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
 // contacts evenly over its lanes.  Contact tables are staged in LDS once per workgroup.
 #define CON_THREADS 1024
 #define CON_WAVES (CON_THREADS / 64)
+#define CAND_CHUNK 128
 
 struct ConShared {
     uint32_t thr[REINA_MAX_AGES][REINA_MAX_ENTRIES];
-    uint32_t meta[REINA_MAX_AGES][REINA_MAX_ENTRIES];
+    uint32_t meta_row[REINA_MAX_ENTRIES];   // shared (place, range) pattern when every age has the same
     float mask_p[REINA_MAX_AGES][8];
     float p_sus[REINA_MAX_VARIANTS][REINA_MAX_AGES];
     int32_t age_start[REINA_MAX_AGES + 1];
@@ -866,17 +1136,18 @@ struct ConShared {
     int32_t n_contacts;
 };
 
-__global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, const Tables *T, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, const Tables *T, reina_buffers_t B, reina_day_t dp,
+                                                          uint32_t scan_waves, uint32_t scan_tiles, int uniform_meta) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     ConShared &S = *reinterpret_cast<ConShared *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int W = B.control[REINA_L_WORK];
-    if ((int)(blockIdx.x * CON_WAVES * 64) >= W) return;  // no batch for this workgroup
+    if (blockIdx.x * CON_WAVES >= scan_waves) return;  // no slice for this workgroup
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(T);
+        const uint4 *src = reinterpret_cast<const uint4 *>(&T->thr[0][0]);
         uint4 *dst = reinterpret_cast<uint4 *>(&S.thr[0][0]);
-        const int n16 = (int)(sizeof(Tables) / 16);
+        const int n16 = (int)(P->nr_ages * REINA_MAX_ENTRIES * 4 / 16);
         for (int k = tid; k < n16; k += CON_THREADS) dst[k] = src[k];
+        if (tid < REINA_MAX_ENTRIES) S.meta_row[tid] = T->meta[0][tid];
         for (int k = tid; k < REINA_MAX_AGES * 8; k += CON_THREADS) (&S.mask_p[0][0])[k] = (&P->mask_p[0][0])[k];
         for (int k = tid; k < REINA_MAX_VARIANTS * REINA_MAX_AGES; k += CON_THREADS) (&S.p_sus[0][0])[k] = (&P->dis.p_susceptibility[0][0])[k];
         for (int k = tid; k <= REINA_MAX_AGES; k += CON_THREADS) S.age_start[k] = P->age_start[k];
@@ -887,77 +1158,127 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
     __syncthreads();
     const reina_disease_t &d = P->dis;
     const uint4 *items = reinterpret_cast<const uint4 *>(B.work_items);
-    const int total_waves = gridDim.x * CON_WAVES;
-    for (int batch = blockIdx.x * CON_WAVES + wave; batch * 64 < W; batch += total_waves) {
-        const int idx = batch * 64 + lane;
-        uint4 it = make_uint4(0, 0, 0, 0);
-        if (idx < W) it = items[idx];
-        uint32_t nr = it.y & 0xFFu;
-        // inclusive prefix sum of nr across the wave
-        uint32_t inc = nr;
+    const uint32_t total_waves = gridDim.x * CON_WAVES;
+    const uint32_t tq = scan_tiles / scan_waves, tr = scan_tiles % scan_waves;
+    // candidate slots are reserved CAND_CHUNK at a time (one atomic per chunk, not per hit)
+    uint32_t cbase = 0, cused = CAND_CHUNK;
+    uint32_t wave_contacts = 0;
+    for (uint32_t sw = blockIdx.x * CON_WAVES + wave; sw < scan_waves; sw += total_waves) {
+        const uint32_t slice_base = 512u * (sw * tq + (sw < tr ? sw : tr));
+        const uint32_t W = B.work_counts[sw];
+        for (uint32_t b0 = 0; b0 < W; b0 += 64) {
+            const uint32_t idx = b0 + lane;
+            uint4 it = make_uint4(0, 0, 0, 0);
+            if (idx < W) it = items[slice_base + idx];
+            uint32_t nr = it.y & 0xFFu;
+            // inclusive prefix sum of nr across the wave
+            uint32_t inc = nr;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            S.pre[wave][lane] = inc;
+            S.item[wave][lane] = it;
+            const uint32_t total = __shfl(inc, 63);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private LDS rows written
+            __builtin_amdgcn_wave_barrier();
+            wave_contacts += total;
+            for (uint32_t j0 = 0; j0 < total; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool act = j < total;
+                bool hit = false;
+                uint4 cand = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+                int place = -1;
+                if (act) {
+                    // owner item: first lane whose inclusive prefix exceeds j
+                    int lo = 0, hi = 63;
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (S.pre[wave][mid] > j) hi = mid; else lo = mid + 1;
+                    }
+                    const int owner = lo;
+                    const uint32_t c = j - (owner ? S.pre[wave][owner - 1] : 0u);
+                    const uint4 own = S.item[wave][owner];
+                    const uint32_t src = own.x;
+                    const float src_inf = rp_u2f(own.z);
+                    const int v = (int)((own.y >> 8) & 0xFFu), row = (int)(own.y >> 16);
+                    rp_u4 r = rp_philox(P->k0, P->k1, src, dp.day, RP_P_CONTACT, c);
+                    // first entry with r0 < threshold (thresholds are non-decreasing); none -> last entry
+                    const int cnt = S.tcount[row];
+                    int l2 = 0, h2 = cnt - 1;
+                    while (l2 < h2) {
+                        int mid = (l2 + h2) >> 1;
+                        if (r.v[0] < S.thr[row][mid]) h2 = mid; else l2 = mid + 1;
+                    }
+                    const uint32_t m = uniform_meta ? S.meta_row[l2] : T->meta[row][l2];
+                    place = (int)(m & 0xFFu);
+                    const int cmin = (int)((m >> 8) & 0xFFu), cmax = (int)((m >> 16) & 0xFFu);
+                    const uint32_t start = (uint32_t)S.age_start[cmin], end = (uint32_t)S.age_start[cmax + 1];
+                    if (end > start) {
+                        const uint32_t t = start + r.v[1] % (end - start);
+                        // 1 bit per agent: the whole table (N/8 bytes) stays in L2 / Infinity Cache
+                        if ((B.sus_bits[t >> 5] >> (t & 31u)) & 1u) {
+                            const int age_t = age_of(S.age_start, t, cmin, cmax);
+                            float p = src_inf * S.p_sus[v][age_t] * d.infectiousness_multiplier[v];
+                            if (rp_chance(p, r.v[2])) {
+                                hit = true;
+                                const float mp = S.mask_p[row][place];
+                                if (mp != 0.0f) {
+                                    float a = mp * d.p_mask_protects_others[v];
+                                    float b = mp * d.p_mask_protects_wearer[v];
+                                    float pm = a + b - a * b;
+                                    if (rp_chance(pm, r.v[3])) hit = false;
+                                }
+                                if (hit) {
+                                    const uint32_t prio = rp_priority20(P->k0, P->k1, src, dp.day);
+                                    atomicMin((unsigned long long *)&B.claim[t], (unsigned long long)rp_order_key(dp.day, prio, src));
+                                    cand = make_uint4(t, src, (uint32_t)v, prio);
+                                }
+                            }
+                        }
+                    }
+                }
+                // daily_contacts[place] (main.pyx:1571): one LDS atomic per place per wave step
+#pragma unroll
+                for (int pl = 0; pl < REINA_NR_PLACES; pl++) {
+                    uint64_t pm_ = __ballot(place == pl);
+                    if (pm_ && lane == 0) atomicAdd(&S.daily[pl], (int)__popcll(pm_));
+                }
+                // candidate records
+                const uint64_t hm = __ballot(hit);
+                if (hm) {
+                    const uint32_t need = (uint32_t)__popcll(hm);
+                    if (cused + need > CAND_CHUNK) {
+                        // close the current chunk with holes, open a new one
+                        if (cused < CAND_CHUNK && (uint32_t)lane < CAND_CHUNK - cused && cbase + cused + lane < P->max_candidates)
+                            reinterpret_cast<uint4 *>(B.candidates)[cbase + cused + lane] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+                        if (cused + 64 < CAND_CHUNK && (uint32_t)lane + 64 < CAND_CHUNK - cused && cbase + cused + 64 + lane < P->max_candidates)
+                            reinterpret_cast<uint4 *>(B.candidates)[cbase + cused + 64 + lane] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+                        uint32_t nb = 0;
+                        if (lane == 0) nb = (uint32_t)atomicAdd(&B.control[REINA_L_CAND], CAND_CHUNK);
+                        cbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+                        cused = 0;
+                    }
+                    if (hit) {
+                        uint32_t pos = cbase + cused + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                        if (pos >= P->max_candidates)
+                            set_problem(B.counters, REINA_PROBLEM_CANDIDATE_OVERFLOW);
+                        else
+                            reinterpret_cast<uint4 *>(B.candidates)[pos] = cand;
+                    }
+                    cused += need;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        S.pre[wave][lane] = inc;
-        S.item[wave][lane] = it;
-        const uint32_t total = __shfl(inc, 63);
-        // wave-private LDS row: same-wave visibility only needs the LDS write to have landed
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t j = lane; j < total; j += 64) {
-            // owner item: first lane whose inclusive prefix exceeds j
-            int lo = 0, hi = 63;
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (S.pre[wave][mid] > j) hi = mid; else lo = mid + 1;
-            }
-            const int owner = lo;
-            const uint32_t c = j - (owner ? S.pre[wave][owner - 1] : 0u);
-            const uint4 own = S.item[wave][owner];  // (a shuffle would read 0 from lanes idle in the tail)
-            const uint32_t src = own.x;
-            const uint32_t packed = own.y;
-            const float src_inf = rp_u2f(own.z);
-            const int v = (int)((packed >> 8) & 0xFFu), row = (int)(packed >> 16);
-            rp_u4 r = rp_philox(P->k0, P->k1, src, dp.day, RP_P_CONTACT, c);
-            // first entry with r0 < threshold (thresholds are non-decreasing); none -> last entry
-            const int cnt = S.tcount[row];
-            int l2 = 0, h2 = cnt - 1;
-            while (l2 < h2) {
-                int mid = (l2 + h2) >> 1;
-                if (r.v[0] < S.thr[row][mid]) h2 = mid; else l2 = mid + 1;
-            }
-            const uint32_t m = S.meta[row][l2];
-            const int place = (int)(m & 0xFFu), cmin = (int)((m >> 8) & 0xFFu), cmax = (int)((m >> 16) & 0xFFu);
-            const uint32_t start = (uint32_t)S.age_start[cmin], end = (uint32_t)S.age_start[cmax + 1];
-            atomicAdd(&S.daily[place], 1);
-            if (end <= start) continue;
-            const uint32_t t = start + r.v[1] % (end - start);
-            const uint32_t wt = B.hot[t];
-            if (RH_STATE(wt) != RS_SUSCEPTIBLE) continue;
-            const int age_t = age_of(S.age_start, t, cmin, cmax);
-            float p = src_inf * S.p_sus[v][age_t] * d.infectiousness_multiplier[v];
-            if (!rp_chance(p, r.v[2])) continue;
-            const float mp = S.mask_p[row][place];
-            if (mp != 0.0f) {
-                float a = mp * d.p_mask_protects_others[v];
-                float b = mp * d.p_mask_protects_wearer[v];
-                float pm = a + b - a * b;
-                if (rp_chance(pm, r.v[3])) continue;
-            }
-            const uint32_t prio = rp_priority20(P->k0, P->k1, src, dp.day);
-            atomicMin((unsigned long long *)&B.claim[t], (unsigned long long)rp_order_key(dp.day, prio, src));
-            uint32_t pos = wave_alloc(&B.control[REINA_L_CAND]);
-            if (pos >= P->max_candidates) {
-                set_problem(B.counters, REINA_PROBLEM_CANDIDATE_OVERFLOW);
-                continue;
-            }
-            reinterpret_cast<uint4 *>(B.candidates)[pos] = make_uint4(t, src, (uint32_t)v, prio);
-        }
-        if (lane == 0 && total) atomicAdd(&S.n_contacts, (int)total);
-        __builtin_amdgcn_wave_barrier();
     }
+    // holes in the last open chunk
+    if (cused < CAND_CHUNK) {
+        for (uint32_t k = cused + lane; k < CAND_CHUNK; k += 64)
+            if (cbase + k < P->max_candidates) reinterpret_cast<uint4 *>(B.candidates)[cbase + k] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+    }
+    if (lane == 0 && wave_contacts) atomicAdd(&S.n_contacts, (int)wave_contacts);
     __syncthreads();
     if (tid < REINA_NR_PLACES && S.daily[tid]) atomicAdd(&B.counters[SC_IDX(REINA_S_DAILY_CONTACTS + tid)], S.daily[tid]);
     if (tid == 0 && S.n_contacts) atomicAdd(&B.control[REINA_L_CONTACTS], S.n_contacts);
@@ -967,22 +1288,22 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
 // k_install: the attempt whose source holds the smallest (priority, id) key per target wins
 // (the reference: first source in rotated scan order, main.pyx:1982-1992) and infects it.
 __global__ void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    __shared__ int32_t new_by_age[REINA_MAX_AGES];
+    __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
+    if (threadIdx.x < REINA_MAX_AGES) new_by_age[threadIdx.x] = 0;
+    if (threadIdx.x < REINA_MAX_VARIANTS) new_by_variant[threadIdx.x] = 0;
+    __syncthreads();
     const int C = min(B.control[REINA_L_CAND], (int)P->max_candidates);
     const uint4 *cand = reinterpret_cast<const uint4 *>(B.candidates);
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < C; k += gridDim.x * blockDim.x) {
         uint4 cd = cand[k];
+        if (cd.x == 0xFFFFFFFFu) continue;  // hole left by the chunked reservation
         if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
         uint32_t w = ld_hot(&B.hot[cd.x]);
         if (RH_STATE(w) != RS_SUSCEPTIBLE) continue;  // duplicate record of the same winner
-        install_infection(P, B, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode);
+        install_infection(P, B, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode, new_by_age, new_by_variant);
     }
-}
-
-__global__ void k_day_end(reina_buffers_t B, reina_day_t dp) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        B.counters[SC_IDX(REINA_S_DAY)] = (int32_t)dp.day + 1;
-        B.counters[SC_IDX(REINA_S_QUEUE_LEN)] = B.control[((dp.day & 1) ^ 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
-    }
+    flush_new_infections(B, new_by_age, new_by_variant, (int)blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1060,7 +1381,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sizeof(ConShared)));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hospital), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(REINA_MAX_HOSP_EVENTS * 9)));
+                                  (int)(REINA_MAX_HOSP_EVENTS * 8)));
     *out = e;
     return REINA_OK;
 }
@@ -1104,6 +1425,11 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     std::memcpy(e->h_params.mask_p, t->mask_p, sizeof(float) * A * 8);
     std::memcpy(e->h_tables.thr, t->threshold, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
     std::memcpy(e->h_tables.meta, t->meta, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
+    e->uniform_meta = 1;  // every participant age lists the same (place, contact range) sequence?
+    for (uint32_t a = 1; a < A && e->uniform_meta; a++)
+        if (t->count[a] != t->count[0] ||
+            std::memcmp(e->h_tables.meta[a], e->h_tables.meta[0], sizeof(uint32_t) * (size_t)t->count[0]) != 0)
+            e->uniform_meta = 0;
     // pageable source: the runtime stages the bytes before returning, so the host copies above
     // may be overwritten by the next upload while earlier days are still queued on the stream
     HIP_CHECK(hipMemcpyAsync(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice, s));
@@ -1131,24 +1457,32 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
             hipLaunchKernelGGL(k_test_trace<0>, dim3(g), dim3(256), 0, s, e->d_params, e->buf, dp);
             hipLaunchKernelGGL(k_test_trace<1>, dim3(g), dim3(256), 0, s, e->d_params, e->buf, dp);
         }
-        hipLaunchKernelGGL(k_test_finish, dim3(1), dim3(64), 0, s, e->buf, dp);
     }
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
     if (e->profile) {
         ev_s0 = take_event(e);
         hipEventRecord(e->ev_pool[ev_s0], s);
     }
-    hipLaunchKernelGGL(k_scan, dim3(grid_for(N / 4 + 1, SCAN_THREADS, 2048)), dim3(SCAN_THREADS), 0, s, e->d_params, e->buf, dp);
+    // scan geometry: tiles of 512 agents; every wave gets >= 4 tiles when the population is small
+    const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
+    uint32_t scan_blocks = (scan_tiles / 4u + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (scan_blocks < 1) scan_blocks = 1;
+    if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
+    const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
+    hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SCAN_THREADS), 0, s, e->d_params, e->buf, dp);
     if (e->profile) {
         ev_s1 = take_event(e);
         hipEventRecord(e->ev_pool[ev_s1], s);
         e->scan_pairs.emplace_back(ev_s0, ev_s1);
     }
-    hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 9, s, e->d_params, e->buf, dp);
-    hipLaunchKernelGGL(k_contacts, dim3(grid_for(N / 16 + 1, CON_THREADS, 256)), dim3(CON_THREADS), sizeof(ConShared), s,
-                       e->d_params, e->d_tables, e->buf, dp);
+    hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s, e->d_params, e->buf, dp);
+    {
+        uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
+        if (con_blocks > 512) con_blocks = 512;
+        hipLaunchKernelGGL(k_contacts, dim3(con_blocks), dim3(CON_THREADS), sizeof(ConShared), s,
+                           e->d_params, e->d_tables, e->buf, dp, scan_waves, scan_tiles, e->uniform_meta);
+    }
     hipLaunchKernelGGL(k_install, dim3(grid_for(N / 64 + 1, 256, 512)), dim3(256), 0, s, e->d_params, e->buf, dp);
-    hipLaunchKernelGGL(k_day_end, dim3(1), dim3(64), 0, s, e->buf, dp);
     if (e->profile) {
         size_t ev_day1 = take_event(e);
         hipEventRecord(e->ev_pool[ev_day1], s);

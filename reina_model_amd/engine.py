@@ -26,6 +26,7 @@ MAX_IMPORT_CLASSES = 16
 MAX_IMPORT_BATCHES = 16
 MAX_VACCINATIONS = 16
 MAX_HOSP_EVENTS = 16384
+MAX_SCAN_WAVES = 8192
 
 C_NAMES = ('infected', 'detected', 'all_detected', 'all_infected', 'in_ward', 'hospitalized',
            'in_icu', 'cum_icu', 'dead', 'susceptible', 'recovered', 'vaccinated',
@@ -82,7 +83,7 @@ class ContactTablesABI(ctypes.Structure):
 
 BUFFER_FIELDS = ('hot', 'infector', 'n_infected', 'onset_days', 'vacc_day', 'first_infectee',
                  'next_sibling', 'claim', 'counters', 'control', 'work_items', 'candidates',
-                 'queue0', 'queue1', 'level1', 'hosp_events')
+                 'queue0', 'queue1', 'level1', 'hosp_events', 'work_counts', 'sus_bits')
 
 
 class Buffers(ctypes.Structure):
@@ -203,6 +204,8 @@ class Engine:
             candidates=a.zeros(4 * config.max_candidates, np.uint32),
             queue0=a.zeros(config.max_queue, np.uint32), queue1=a.zeros(config.max_queue, np.uint32),
             level1=a.zeros(config.max_queue, np.uint32), hosp_events=a.zeros(MAX_HOSP_EVENTS, np.uint64),
+            work_counts=a.zeros(MAX_SCAN_WAVES, np.uint32),
+            sus_bits=a.zeros((n + 31) // 32 + 1, np.uint32),
         )
         bufs = Buffers(**{k: a.ptr(v) for k, v in self.tensors.items()})
         self._check(self.f['bind_buffers'](self._h, ctypes.byref(bufs)), 'bind_buffers')

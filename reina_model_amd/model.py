@@ -205,8 +205,8 @@ class Context:
         cfg.nr_ages = nr_ages
         cfg.nr_variants = self.nr_variants
         cfg.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
-        cfg.max_work_items = total + 64
-        cfg.max_candidates = total + 64
+        cfg.max_work_items = total + 1024
+        cfg.max_candidates = total + 1024 * 1024
         cfg.max_queue = total + 64
         for a in range(_eng.MAX_AGES + 1):
             cfg.age_start[a] = int(self.age_start[a])
