@@ -159,10 +159,10 @@ __device__ __forceinline__ uint32_t clamp_days(int32_t *counters, int d) {
 
 // person_infect (main.pyx:209-235) + Population.infect (:1576-1582).  `expect` is the susceptible
 // word the caller saw; the CAS makes duplicate winner records install once.
-__device__ bool install_infection(const DevParams *P, const reina_buffers_t &B, uint32_t t, uint32_t expect,
+__device__ bool install_infection(const DevParams *P, const reina_buffers_t &B, const int32_t *age_start, uint32_t t, uint32_t expect,
                                   uint32_t day, uint32_t variant, int32_t src, int fresh,
                                   uint32_t testing_mode, int32_t *new_by_age, int32_t *new_by_variant) {
-    int age = age_of(P->age_start, t, 0, (int)P->nr_ages - 1);
+    int age = age_of(age_start, t, 0, (int)P->nr_ages - 1);
     rp_u4 r = rp_philox(P->k0, P->k1, t, day, RP_P_INFECT, 0);
     float val = rp_uniform24(r.v[0]);
     float vmod = 1.0f;
@@ -263,7 +263,7 @@ __global__ void k_init(const DevParams *P, reina_buffers_t B, int32_t beds, int3
 // lowest import number proposing it (atomicMin on the claim word); the rest retry next round.
 __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, int pre_init,
                             uint32_t *import_base, uint8_t *placed, uint32_t *s_unplaced,
-                            int32_t *new_by_age, int32_t *new_by_variant) {
+                            int32_t *new_by_age, int32_t *new_by_variant, const int32_t *s_age_start) {
     uint32_t total = 0;
     for (uint32_t b = 0; b < dp.n_import_batches; b++)
         if ((int)dp.import_batches[b].pre_init == pre_init) total += dp.import_batches[b].count;
@@ -287,8 +287,8 @@ __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const 
                     c = k;
                     break;
                 }
-            uint32_t start = (uint32_t)P->age_start[d.import_class_min_age[c]];
-            uint32_t end = (uint32_t)P->age_start[d.import_class_max_age[c] + 1];
+            uint32_t start = (uint32_t)s_age_start[d.import_class_min_age[c]];
+            uint32_t end = (uint32_t)s_age_start[d.import_class_max_age[c] + 1];
             placed[j] = 2;  // proposing nothing
             if (end <= start) continue;
             uint32_t t = start + r.v[1] % (end - start);
@@ -313,8 +313,8 @@ __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const 
                     c = k;
                     break;
                 }
-            uint32_t start = (uint32_t)P->age_start[d.import_class_min_age[c]];
-            uint32_t end = (uint32_t)P->age_start[d.import_class_max_age[c] + 1];
+            uint32_t start = (uint32_t)s_age_start[d.import_class_min_age[c]];
+            uint32_t end = (uint32_t)s_age_start[d.import_class_max_age[c] + 1];
             uint32_t t = start + r.v[1] % (end - start);
             if (ld_claim(&B.claim[t]) == rp_order_key(dp.day, 0xFFFFFu - round, j)) {
                 // variant of import j: walk the batches of this phase
@@ -328,7 +328,7 @@ __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const 
                     }
                 }
                 uint32_t w = ld_hot(&B.hot[t]);
-                install_infection(P, B, t, w, dp.day, variant, -1, 1, dp.testing_mode, new_by_age, new_by_variant);
+                install_infection(P, B, s_age_start, t, w, dp.day, variant, -1, 1, dp.testing_mode, new_by_age, new_by_variant);
                 placed[j] = 1;
             }
         }
@@ -412,7 +412,9 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
     __shared__ uint32_t s_import_base;
     __shared__ int32_t new_by_age[REINA_MAX_AGES];
     __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     const int tid = threadIdx.x;
+    if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
     if (tid < REINA_MAX_AGES) new_by_age[tid] = 0;
     if (tid < REINA_MAX_VARIANTS) new_by_variant[tid] = 0;
     // generate_state() is taken BEFORE iterate() (calc/simulation.py:195 vs :270)
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
         B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] += dp.add_icu_units;
     }
     __syncthreads();
-    pro_imports(P, B, dp, 1, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant);
+    pro_imports(P, B, dp, 1, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
     // Population.init_day (main.pyx:1687-1699) + Context._iterate zeroing (:1998-2000)
     __syncthreads();
     for (int k = tid; k < (int)P->nr_ages; k += PRO_THREADS) {
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
         B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] = B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
     }
     __syncthreads();
-    pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant);
+    pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
     // note: vaccination follows the test-queue pass in the reference (main.pyx:547-558); it only
     // reads DETECTED bits, so it is launched from k_vaccinate after the k_test_* kernels.
 }
@@ -481,6 +483,9 @@ __device__ __forceinline__ void queue_append(const DevParams *P, const reina_buf
 // Q1: every queued test is positive (quirk Q8): clear QUEUED, set DETECTED
 __global__ __launch_bounds__(256) void k_test_detect(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
     __shared__ int32_t s_det[REINA_MAX_AGES];
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
+    if (B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] <= (int)(blockIdx.x * blockDim.x)) return;
+    if (threadIdx.x <= REINA_MAX_AGES) s_age_start[threadIdx.x] = P->age_start[threadIdx.x];
     if (threadIdx.x < REINA_MAX_AGES) s_det[threadIdx.x] = 0;
     __syncthreads();
     const int cur = dp.day & 1;
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(256) void k_test_detect(const DevParams *P, reina_b
         uint32_t w = B.hot[i];
         if (w & RH_DETECTED) set_problem(B.counters, 7 /* WRONG_STATE */);
         B.hot[i] = (w & ~RH_QUEUED) | RH_DETECTED;
-        atomicAdd(&s_det[age_of(P->age_start, i, 0, (int)P->nr_ages - 1)], 1);
+        atomicAdd(&s_det[age_of(s_age_start, i, 0, (int)P->nr_ages - 1)], 1);
     }
     __syncthreads();
     if (threadIdx.x < REINA_MAX_AGES && s_det[threadIdx.x]) {
@@ -775,9 +780,9 @@ __device__ __forceinline__ uint32_t scan_word(const DevParams *P, const reina_bu
             }
         }
     }
-    wq_push(Q.exp_, Q.n_exp, p_exp, i, w);
-    wq_push(Q.ill, Q.n_ill, p_ill, i, nw);
-    wq_push(Q.ev, Q.n_ev, p_ev, i, ev_type);
+    if (__any(p_exp)) wq_push(Q.exp_, Q.n_exp, p_exp, i, w);
+    if (__any(p_ill)) wq_push(Q.ill, Q.n_ill, p_ill, i, nw);
+    if (__any(p_ev)) wq_push(Q.ev, Q.n_ev, p_ev, i, ev_type);
     return p_ill ? w : nw;
 }
 
@@ -816,37 +821,38 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
         uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
         if (v0) a = hot4[q0];
         if (v1) b = hot4[q1];
-        // nothing to do in this tile for the whole wave? (all susceptible / counted)
-        const bool any = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u;
-        if (!__any(any)) continue;
-        uint4 na, nb;
-        na.x = scan_word(P, B, S, Q, v0, 4 * q0 + 0, a.x);
-        scan_drain(P, B, dp, S, Q, 64);
-        na.y = scan_word(P, B, S, Q, v0, 4 * q0 + 1, a.y);
-        scan_drain(P, B, dp, S, Q, 64);
-        na.z = scan_word(P, B, S, Q, v0, 4 * q0 + 2, a.z);
-        scan_drain(P, B, dp, S, Q, 64);
-        na.w = scan_word(P, B, S, Q, v0, 4 * q0 + 3, a.w);
-        scan_drain(P, B, dp, S, Q, 64);
-        nb.x = scan_word(P, B, S, Q, v1, 4 * q1 + 0, b.x);
-        scan_drain(P, B, dp, S, Q, 64);
-        nb.y = scan_word(P, B, S, Q, v1, 4 * q1 + 1, b.y);
-        scan_drain(P, B, dp, S, Q, 64);
-        nb.z = scan_word(P, B, S, Q, v1, 4 * q1 + 2, b.z);
-        scan_drain(P, B, dp, S, Q, 64);
-        nb.w = scan_word(P, B, S, Q, v1, 4 * q1 + 3, b.w);
-        scan_drain(P, B, dp, S, Q, 64);
-        // component stores: a deferred (onset) word keeps its old value here and is written by
-        // become_ill; unchanged words are not written at all
-        uint32_t *h = B.hot;
-        if (na.x != a.x) h[4 * q0 + 0] = na.x;
-        if (na.y != a.y) h[4 * q0 + 1] = na.y;
-        if (na.z != a.z) h[4 * q0 + 2] = na.z;
-        if (na.w != a.w) h[4 * q0 + 3] = na.w;
-        if (nb.x != b.x) h[4 * q1 + 0] = nb.x;
-        if (nb.y != b.y) h[4 * q1 + 1] = nb.y;
-        if (nb.z != b.z) h[4 * q1 + 2] = nb.z;
-        if (nb.w != b.w) h[4 * q1 + 3] = nb.w;
+        // which of this lane's 8 words need the state machine today: infected (state 1..4) or
+        // removed but not yet counted into R.  Susceptible / counted words cost these few ops.
+        uint32_t mask = 0;
+#define NEED_BIT(wd, k)                                                                       \
+        {                                                                                     \
+            uint32_t st_ = (wd) & 7u;                                                         \
+            bool need_ = (st_ - 1u) < 4u || (st_ >= (uint32_t)RS_RECOVERED && !((wd) & RH_INCLUDED)); \
+            mask |= (need_ ? 1u : 0u) << (k);                                                 \
+        }
+        NEED_BIT(a.x, 0) NEED_BIT(a.y, 1) NEED_BIT(a.z, 2) NEED_BIT(a.w, 3)
+        NEED_BIT(b.x, 4) NEED_BIT(b.y, 5) NEED_BIT(b.z, 6) NEED_BIT(b.w, 7)
+#undef NEED_BIT
+        // every round each lane takes its next needy word: rounds = max needy words per lane
+        // (1-2 at a few % prevalence) instead of one pass per word position
+        while (__any(mask != 0u)) {
+            const bool valid = mask != 0u;
+            const int k = valid ? (int)__ffs(mask) - 1 : 0;
+            mask &= mask - 1u;
+            uint32_t w = a.x;
+            w = k == 1 ? a.y : w;
+            w = k == 2 ? a.z : w;
+            w = k == 3 ? a.w : w;
+            w = k == 4 ? b.x : w;
+            w = k == 5 ? b.y : w;
+            w = k == 6 ? b.z : w;
+            w = k == 7 ? b.w : w;
+            const uint32_t i = k < 4 ? 4u * q0 + (uint32_t)k : 4u * q1 + (uint32_t)(k - 4);
+            const uint32_t nw = scan_word(P, B, S, Q, valid, i, w);
+            scan_drain(P, B, dp, S, Q, 64);
+            // a deferred (onset) word keeps its old value here and is written by become_ill
+            if (valid && nw != w) B.hot[i] = nw;
+        }
     }
     if (wave_global == 0) {  // ragged tail: N not a multiple of 4
         uint32_t i = (n4 << 2) + lane;
@@ -937,6 +943,7 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
     __shared__ int s_b, s_c;
     __shared__ SatFn s_fb[HOSP_THREADS], s_fc[HOSP_THREADS];
     __shared__ int32_t s_cnt[HL_NR][REINA_MAX_AGES];
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     const int tid = threadIdx.x;
     int M = B.control[REINA_L_HOSP];
     if (M > REINA_MAX_HOSP_EVENTS) M = REINA_MAX_HOSP_EVENTS;
@@ -948,6 +955,7 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
     const bool ordered = !(b0 >= B.control[REINA_L_HOSP_ADMIT] && c0 >= B.control[REINA_L_ICU_ADMIT]);
     for (int k = tid; k < M2; k += HOSP_THREADS) ev[k] = k < M ? B.hosp_events[k] : ~0ull;
     for (int k = tid; k < HL_NR * REINA_MAX_AGES; k += HOSP_THREADS) (&s_cnt[0][0])[k] = 0;
+    if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
     __syncthreads();
     if (ordered) {
         for (int size = 2; size <= M2; size <<= 1) {
@@ -1043,7 +1051,7 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
         const bool granted = !(e >> 63);
         uint32_t i = (uint32_t)((e >> 2) & 0xFFFFFFFFu);
         uint32_t w = B.hot[i];
-        int age = age_of(P->age_start, i, 0, (int)P->nr_ages - 1), v = RH_VARIANT(w), sev = RH_SEV(w);
+        int age = age_of(s_age_start, i, 0, (int)P->nr_ages - 1), v = RH_VARIANT(w), sev = RH_SEV(w);
         float od = B.onset_days[i];
         int died = -1;  // -1 stays in care, 0 recovers, 1 dies
         if (type == EV_HOSPITALIZE) {
@@ -1290,6 +1298,9 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
 __global__ void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
     __shared__ int32_t new_by_age[REINA_MAX_AGES];
     __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
+    if (B.control[REINA_L_CAND] <= (int)(blockIdx.x * blockDim.x)) return;  // nothing for this workgroup
+    for (int k = threadIdx.x; k <= REINA_MAX_AGES; k += blockDim.x) s_age_start[k] = P->age_start[k];
     if (threadIdx.x < REINA_MAX_AGES) new_by_age[threadIdx.x] = 0;
     if (threadIdx.x < REINA_MAX_VARIANTS) new_by_variant[threadIdx.x] = 0;
     __syncthreads();
@@ -1301,7 +1312,7 @@ __global__ void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp)
         if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
         uint32_t w = ld_hot(&B.hot[cd.x]);
         if (RH_STATE(w) != RS_SUSCEPTIBLE) continue;  // duplicate record of the same winner
-        install_infection(P, B, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode, new_by_age, new_by_variant);
+        install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode, new_by_age, new_by_variant);
     }
     flush_new_infections(B, new_by_age, new_by_variant, (int)blockDim.x);
 }

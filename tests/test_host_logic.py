@@ -1,0 +1,143 @@
+"""Host-side logic of the product: contact-table builder, intervention conversion, day descriptors,
+parameter expansion.  CPU only; the engine is replaced by oracle B where one is needed."""
+import copy
+
+import numpy as np
+import pytest
+
+import par_backend
+from reina_model_amd import contacts, datasets, interventions, model, simulation
+from reina_model_amd import engine as eng
+from reina_model_amd.variables import VARIABLE_DEFAULTS
+
+
+def test_contact_tables_equal_pandas_formulation():
+    """generate_contact_probabilities (main.pyx:1184-1235) uses pandas groupby-sum (Kahan),
+    sort_index, divide, cumsum; the numpy builder must give the same float64 bits."""
+    pd = pytest.importorskip('pandas')
+    rows = datasets.get_contacts_per_day()
+    cm = contacts.ContactMatrix(rows, 101)
+    cm.set_mobility_factor((100 - 80) / 100.0, place=5, min_age=0, max_age=70)
+    cm.set_mobility_factor(0.95)
+    cm.set_mobility_factor(0.0, place=2, min_age=19, max_age=None)
+    cm.set_mask_probability(0.8, min_age=65)
+    assert cm.init_day() is True and cm.init_day() is False
+    t = cm.tables
+    df = pd.DataFrame(rows, columns=['place_type', 'participant_age', 'contact_age', 'contacts'])
+    for place, mn, mx, f in cm.mobility_factors:
+        filt = (df.participant_age >= mn) & (df.participant_age <= mx)
+        if place != contacts.PLACE_ALL:
+            filt &= df.place_type == contacts.PLACES[place]
+        df.loc[filt, 'contacts'] *= float(f)
+    tot = df.groupby('participant_age')['contacts'].sum()
+    d2 = df.set_index(['place_type', 'participant_age', 'contact_age']).sort_index().unstack('participant_age')
+    d2.columns = d2.columns.droplevel(0)
+    d2 = d2.divide(tot, axis=1).cumsum()
+    assert np.array_equal(tot.values, t.nr_contacts_by_age)
+    for age in d2.columns:
+        o = t.offset[age]
+        for k, ((place, (a, b)), cum) in enumerate(d2[age].to_dict().items()):
+            assert contacts.PLACES[t.place[o + k]] == place and t.cmin[o + k] == a and t.cmax[o + k] == b
+            assert t.cum_p[o + k] == cum
+    assert t.mask_p[t.offset[70]] == np.float32(0.8) and t.mask_p[t.offset[64]] == 0
+
+
+def test_mobility_factor_is_float32_like_the_reference():
+    cm = contacts.ContactMatrix(datasets.get_contacts_per_day(), 101)
+    cm.set_mobility_factor((100 - 30) / 100.0)
+    assert 1 - float(cm.mobility_factor) == 0.30000001192092896  # value seen in the reference goldens
+
+
+def test_intervention_tuples_round_trip():
+    iv = interventions.iv_tuple_to_obj(['limit-mobility', '2020-03-15', 80, 0, 70, 'other'])
+    assert iv.type == 'limit-mobility' and iv.date == '2020-03-15'
+    assert iv.get_param_values() == dict(reduction=80, min_age=0, max_age=70, place='other')
+    iv = interventions.iv_tuple_to_obj(['wear-masks', '2020-07-01', 80, 65, None, None])
+    assert iv.get_param_values() == dict(share_of_contacts=80, min_age=65, max_age=None)
+    iv = interventions.iv_tuple_to_obj(['import-infections-weekly', '2020-03-10', 30, 40])
+    assert iv.get_param_values() == {'weekly_amount': 30, 'variant_b1.1.7': 40}
+    iv = interventions.iv_tuple_to_obj(['test-all-with-symptoms', '2020-02-20'])
+    assert iv.get_param_values() == {}
+    with pytest.raises(Exception):
+        interventions.iv_tuple_to_obj(['no-such-thing', '2020-01-01'])
+    with pytest.raises(Exception):
+        interventions.iv_tuple_to_obj(['limit-mobility', '2020-01-01', 10, None, None, 'moon'])
+    ivs = interventions.get_active_interventions(copy.deepcopy(VARIABLE_DEFAULTS))
+    assert len(ivs) == 40 and ivs[0].id == '0'
+
+
+def test_disease_struct_expansion():
+    d, names = model.build_disease_struct(simulation.create_disease_params(VARIABLE_DEFAULTS), 101,
+                                          VARIABLE_DEFAULTS['imported_infection_ages'])
+    assert names == ['wild-type', 'b1.1.7']
+    assert d.p_asymptomatic_infection[0] == np.float32(0.008)  # quirk Q1: 0.8 is treated as a percentage
+    assert d.infectiousness_multiplier[1] == np.float32(0.9075)
+    assert d.p_susceptibility[0][9] == np.float32(0.34) and d.p_susceptibility[0][10] == np.float32(0.67)
+    assert d.p_susceptibility[0][100] == np.float32(1.47)
+    assert d.p_severe_given_symptomatic[45] == np.float32(0.0343 / 0.70)
+    assert d.infectiousness_over_time[0][10] == np.float32(0.18539)
+    assert list(d.import_class_min_age[:5]) == [0, 20, 40, 60, 70]
+    assert list(d.import_class_max_age[:5]) == [19, 39, 59, 69, 100]
+    assert d.import_class_cum[3] == np.float32(1.0)
+
+
+def test_day_descriptors_follow_the_schedule():
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ivs = [['import-infections', '2020-02-18', 7], ['import-infections', '2020-02-18', 3, 'b1.1.7'],
+           ['import-infections-weekly', '2020-02-18', 21, 100],
+           ['vaccinate', '2020-02-19', 700, 70, None], ['vaccinate', '2020-02-19', 70, None, None],
+           ['build-new-hospital-beds', '2020-02-19', 5], ['test-with-contact-tracing', '2020-02-20', 30],
+           ['limit-mobility', '2020-02-20', 50]]
+    ctx = simulation.make_context(v, age_counts=datasets.scaled_population(5000), seed=1, interventions=ivs,
+                                  engine_factory=par_backend.par_engine_factory)
+    d0, changed = ctx._build_day()
+    ctx.day += 1
+    assert not changed
+    b = [(x.count, x.variant, x.pre_init) for x in d0.import_batches[:d0.n_import_batches]]
+    assert b == [(7, 0, 1), (3, 1, 1), (3, 1, 0)]  # weekly 21/7 = 3/day, all variant share 100 %
+    assert d0.testing_mode == model.NO_TESTING and d0.n_vaccinations == 0
+    d1, changed = ctx._build_day()
+    ctx.day += 1
+    assert d1.add_beds == 5 and d1.n_vaccinations == 2
+    assert (d1.vaccinations[0].nr, d1.vaccinations[0].slot) == (100, 0)
+    assert d1.vaccinations[0].idx_start == ctx.age_start[70] and d1.vaccinations[0].idx_end == ctx.total_people
+    assert (d1.vaccinations[1].nr, d1.vaccinations[1].idx_start) == (10, 0)
+    d2, changed = ctx._build_day()
+    assert changed and d2.testing_mode == model.ALL_WITH_SYMPTOMS_CT
+    assert abs(d2.p_successful_tracing - 0.3) < 1e-7
+
+
+def test_unknown_intervention_type_raises_like_the_reference():
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ctx = simulation.make_context(v, age_counts=datasets.scaled_population(3000), seed=1, interventions=[],
+                                  engine_factory=par_backend.par_engine_factory)
+
+    class Fake:
+        type, date = 'limit-mass-gatherings', '2020-02-18'
+
+        def get_param_values(self):
+            return {}
+    with pytest.raises(Exception):
+        ctx.apply_intervention(Fake())
+    with pytest.raises(Exception, match='Variant nope not found'):
+        ctx.find_variant('nope')
+
+
+def test_simulate_individuals_frame_contract():
+    """(df, adf) shapes/columns of calc/simulation.py:186-190,278-290 with the CPU checker engine."""
+    pytest.importorskip('pandas')
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v['simulation_days'] = 30
+    seen = []
+    df, adf = simulation.simulate_individuals(v, step_callback=lambda d: seen.append(len(d)) or True,
+                                              callback_day_interval=10, age_counts=datasets.scaled_population(8000),
+                                              engine_factory=par_backend.par_engine_factory)
+    assert list(df.columns) == simulation.POP_ATTRS + simulation.STATE_ATTRS + simulation.EXPOSURES_ATTRS + ['us_per_infected']
+    assert len(df) == 30 and str(df.index[0].date()) == '2020-02-18'
+    assert adf.shape == (30, 12 * 9)
+    assert df['susceptible'].iloc[0] == datasets.scaled_population(8000).sum()
+    assert (df['susceptible'] + df['infected'] + df['recovered'] + df['dead'] == df['susceptible'].iloc[0]).all()
+    assert len(seen) == 3
+    with pytest.raises(simulation.ExecutionInterrupted):
+        simulation.simulate_individuals(v, step_callback=lambda d: False, age_counts=datasets.scaled_population(8000),
+                                        engine_factory=par_backend.par_engine_factory)

@@ -1,0 +1,68 @@
+"""Tolerance tier between the parallel formulation and the reference.
+
+The reference consumes ONE PCG64 stream in scan order (cythonsim/simrandom.pyx:13-55), which no
+parallel engine can replay; the parallel formulation (oracle B on CPU, the HIP kernels on GPU)
+keys each decision by (agent, day, purpose) instead.  Same model, different random numbers, so
+the claim is distributional.  Stated tolerance, per compared day and quantity, ensembles of n
+seeds:  |mean_par - mean_seq| <= 4 * sqrt(var_par/n_par + var_seq/n_seq) + 0.5 % of the seq mean
+(+1 agent).  mean_seq / var_seq come from the sequential oracle A, which is pinned bit-exact to
+the real cythonsim (test_oracle_seq.py).
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN
+
+DAYS_CHECKED = (20, 40, 60, 80, 100, 120, 160, 200, 239)
+N_SEEDS = 16
+
+
+def _ensemble(engine_factory=None, device='cuda:0'):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_ensemble as me
+    from reina_model_amd import engine as eng, simulation
+    z = np.load(os.path.join(GOLDEN, 'seq_ensemble_200k.npz'))
+    v, ages = me.scenario()
+    runs = []
+    A = eng.MAX_AGES
+    for seed in range(5000, 5000 + N_SEEDS):
+        ctx = simulation.make_context(v, age_counts=ages, seed=seed, engine_factory=engine_factory, device=device)
+        h = ctx.run(me.DAYS)
+        out = np.zeros((me.DAYS, len(me.ATTRS)))
+        for k, a in enumerate(me.ATTRS):
+            i = eng.C_NAMES.index(a)
+            out[:, k] = h[:, i * A:(i + 1) * A].sum(axis=1)
+        runs.append(out)
+    return np.array(runs), z, me.ATTRS
+
+
+def _check(runs, z, attrs):
+    mean_p, var_p = runs.mean(axis=0), runs.var(axis=0, ddof=1)
+    n_p, n_s = runs.shape[0], int(z['n'])
+    worst = 0.0
+    for d in DAYS_CHECKED:
+        for k, a in enumerate(attrs):
+            se = np.sqrt(var_p[d, k] / n_p + z['var'][d, k] / n_s)
+            tol = 4.0 * se + 0.005 * abs(z['mean'][d, k]) + 1.0
+            diff = abs(mean_p[d, k] - z['mean'][d, k])
+            worst = max(worst, diff / tol)
+            assert diff <= tol, 'day %d %s: parallel %.1f vs sequential %.1f (tol %.1f)' % (
+                d, a, mean_p[d, k], z['mean'][d, k], tol)
+    return worst
+
+
+@pytest.mark.slow
+def test_oracle_b_matches_sequential_oracle_statistically():
+    import par_backend
+    runs, z, attrs = _ensemble(engine_factory=par_backend.par_engine_factory)
+    _check(runs, z, attrs)
+
+
+@pytest.mark.gpu
+def test_hip_engine_matches_sequential_oracle_statistically():
+    runs, z, attrs = _ensemble()
+    _check(runs, z, attrs)

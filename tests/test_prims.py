@@ -1,0 +1,109 @@
+"""Numeric primitives shared by the HIP kernels and oracle B (reina_model_amd/csrc/reina_prims.h),
+exercised through oracle B's test hooks on the CPU build: Philox known answers (Random123
+kat_vectors), exp/log accuracy, inverse-normal accuracy, gamma moments, and the contact-count
+sampler against the reference's own `Context.sample('contacts_per_day')` draws."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import par_backend
+from golden_util import GOLDEN
+
+vp = ctypes.c_void_p
+
+
+@pytest.fixture(scope='module')
+def L():
+    lib = par_backend.lib()
+    lib.par_test_philox.argtypes = [vp, vp, vp]
+    for n in ('par_test_expf', 'par_test_logf', 'par_test_normal'):
+        getattr(lib, n).argtypes = [vp, vp, ctypes.c_int]
+    lib.par_test_gamma.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint32,
+                                   ctypes.c_uint32, vp, ctypes.c_int]
+    lib.par_test_nr_contacts.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_int, vp, ctypes.c_int]
+    return lib
+
+
+def test_philox4x32_10_known_answers(L):
+    def ph(key, ctr):
+        k = np.array(key, dtype=np.uint32)
+        c = np.array(ctr, dtype=np.uint32)
+        o = np.zeros(4, dtype=np.uint32)
+        L.par_test_philox(k.ctypes.data, c.ctypes.data, o.ctypes.data)
+        return [int(x) for x in o]
+    assert ph([0, 0], [0, 0, 0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert ph([0xffffffff] * 2, [0xffffffff] * 4) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert ph([0xa4093822, 0x299f31d0], [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_expf_logf_accuracy(L):
+    x = np.linspace(-20, 20, 400001).astype(np.float32)
+    y = np.zeros_like(x)
+    L.par_test_expf(x.ctypes.data, y.ctypes.data, len(x))
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(y - ref) / ref) < 2e-7
+    x = np.exp(np.linspace(-40, 40, 400001)).astype(np.float32)
+    y = np.zeros_like(x)
+    L.par_test_logf(x.ctypes.data, y.ctypes.data, len(x))
+    ref = np.log(x.astype(np.float64))
+    assert np.max(np.abs(y - ref)) < 4e-6
+
+
+def test_inverse_normal_accuracy_and_symmetry(L):
+    from scipy.special import ndtri
+    r = np.linspace(0, 2 ** 32 - 1, 1000001).astype(np.uint64).astype(np.uint32)
+    y = np.zeros(len(r), dtype=np.float32)
+    L.par_test_normal(r.ctypes.data, y.ctypes.data, len(r))
+    ref = ndtri((r.astype(np.float64) + 0.5) / 2 ** 32)
+    assert np.max(np.abs(y - ref)) < 2e-6
+    rc = (np.uint64(2 ** 32 - 1) - r.astype(np.uint64)).astype(np.uint32)
+    yc = np.zeros(len(r), dtype=np.float32)
+    L.par_test_normal(rc.ctypes.data, yc.ctypes.data, len(r))
+    tails = (ref < -1.98) | (ref > 1.98)
+    assert np.array_equal(y[tails], -yc[tails])
+
+
+@pytest.mark.parametrize('mu,cv', [(5.1, 0.86), (21.0, 0.45), (18.8, 0.45)])
+def test_gamma_moments(L, mu, cv):
+    g = np.zeros(400000, dtype=np.float32)
+    L.par_test_gamma(mu, cv, 99, 3, 3, g.ctypes.data, len(g))
+    assert abs(g.mean() - mu) < 0.01 * mu
+    assert abs(g.std() / g.mean() - cv) < 0.01
+    assert g.min() > 0
+
+
+def test_gamma_matches_reference_distribution(L):
+    """round(gamma(5.1, 0.86)) vs the reference's 10 000 `incubation_period` draws (two-sample,
+    chi-square on the day histogram)."""
+    z = np.load(os.path.join(GOLDEN, 'samples.npz'))
+    ref = z['incubation_period|45|']
+    g = np.zeros(200000, dtype=np.float32)
+    L.par_test_gamma(5.1, 0.86, 7, 11, 3, g.ctypes.data, len(g))
+    mine = (g + 0.5).astype(np.int32)
+    bins = np.arange(0, 26)
+    h_ref = np.bincount(np.clip(ref, 0, 25), minlength=26)[bins].astype(np.float64)
+    h_me = np.bincount(np.clip(mine, 0, 25), minlength=26)[bins].astype(np.float64)
+    p = h_me / h_me.sum()
+    exp = p * h_ref.sum()
+    chi2 = ((h_ref - exp) ** 2 / np.maximum(exp, 1e-9))[exp > 5].sum()
+    dof = (exp > 5).sum() - 1
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
+
+
+@pytest.mark.parametrize('age', [5, 25, 45, 65, 85])
+def test_contact_count_matches_reference_samples(L, age):
+    """nr_contacts sampler vs the reference's `contacts_per_day` sample (main.pyx:1308-1320)."""
+    from reina_model_amd import contacts, datasets
+    z = np.load(os.path.join(GOLDEN, 'samples.npz'))
+    ref = z['contacts_per_day|%d|' % age]
+    cm = contacts.ContactMatrix(datasets.get_contacts_per_day(), 101)
+    nrc = np.float32(cm.tables.nr_contacts_by_age[age])
+    y = np.zeros(200000, dtype=np.int32)
+    L.par_test_nr_contacts(5, 1, float(nrc), 1.0, 100, y.ctypes.data, len(y))
+    assert abs(y.mean() - ref.mean()) < 4 * ref.std() / np.sqrt(len(ref)) + 0.02
+    for q in (10, 50, 90, 99):
+        assert abs(np.percentile(y, q) - np.percentile(ref, q)) <= max(1.0, 0.06 * np.percentile(ref, q))
