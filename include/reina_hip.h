@@ -31,6 +31,9 @@ extern "C" {
 #define REINA_MAX_VACCINATIONS 16
 #define REINA_MAX_HOSP_EVENTS 16384
 #define REINA_MAX_SCAN_WAVES 8192
+#define REINA_MAX_SHARDS 16     /* ranks an agent population can be sharded over */
+#define REINA_MAX_RANGES 32     /* distinct contact age ranges (reference: 15) */
+#define REINA_PRESSURE_WORDS (REINA_MAX_SHARDS * REINA_MAX_RANGES * REINA_MAX_VARIANTS)
 
 /* error codes */
 #define REINA_OK 0
@@ -81,11 +84,14 @@ typedef struct {
     uint32_t nr_ages;         /* A */
     uint32_t nr_variants;     /* V */
     uint32_t reserved0;
-    uint64_t seed;            /* Philox key (random_seed of Context, main.pyx:1759) */
+    uint64_t seed;            /* Philox key (random_seed of Context, main.pyx:1759); same on all shards,
+                                 the engine mixes the rank in */            /* Philox key (random_seed of Context, main.pyx:1759) */
     uint32_t max_work_items;  /* capacity of work_items (records) */
     uint32_t max_candidates;  /* capacity of candidates (records) */
     uint32_t max_queue;       /* capacity of each testing queue */
-    uint32_t reserved1;
+    uint32_t n_shards;        /* G >= 1: the population is split over G engine instances (ranks) */
+    uint32_t shard_rank;      /* this instance's rank in [0, G) */
+    uint32_t mirror_slots;    /* power of two: slots per (range, variant) cell of buffers.mirror */
     int32_t age_start[REINA_MAX_AGES + 1]; /* first agent index of each age; [A] = n_agents
                                               (Population.age_start, main.pyx:1332,1442) */
 } reina_config_t;
@@ -126,14 +132,18 @@ typedef struct {
  *   nr_contacts_by_age[A]          float32(total contacts/day)
  *   count[A]                       entries per age (<= REINA_MAX_ENTRIES)
  *   threshold[A][REINA_MAX_ENTRIES] uint32 floor(cum_p * 2^32) (saturated), padded with 0xFFFFFFFF
- *   meta[A][REINA_MAX_ENTRIES]      place | cmin << 8 | cmax << 16
- *   mask_p[A][8]                    float32 mask probability by (participant age, place) */
+ *   meta[A][REINA_MAX_ENTRIES]      place | cmin << 8 | cmax << 16 | range_id << 24
+ *   mask_p[A][8]                    float32 mask probability by (participant age, place)
+ *   range_min/max[n_ranges]         the distinct contact age ranges, indexed by range_id */
 typedef struct {
     const float *nr_contacts_by_age;
     const int32_t *count;
     const uint32_t *threshold;
     const uint32_t *meta;
     const float *mask_p;
+    uint32_t n_ranges;
+    int32_t range_min[REINA_MAX_RANGES];
+    int32_t range_max[REINA_MAX_RANGES];
 } reina_contact_tables_t;
 
 /* Per-agent state and work lists: device pointers owned by the caller. */
@@ -155,6 +165,14 @@ typedef struct {
     uint32_t *queue1;         /* [max_queue] testing queue, odd days */
     uint32_t *level1;         /* [max_queue] contact-tracing level-1 work list */
     uint64_t *hosp_events;    /* [REINA_MAX_HOSP_EVENTS] */
+    int32_t *pressure;        /* [REINA_PRESSURE_WORDS] cross-shard infection pressure of the day:
+                                 [dest shard][contact range][variant] = transmissible contacts aimed at
+                                 agents of another shard. Filled by reina_step_day_begin, summed over
+                                 shards by the caller (one all-reduce), consumed by reina_step_day_end */
+    uint64_t *mirror;         /* [REINA_MAX_RANGES * REINA_MAX_VARIANTS * mirror_slots] sharded runs only:
+                                 a day-tagged hash sample of this shard's OUTGOING cross-shard attempts,
+                                 from which an incoming infection takes a local stand-in infector
+                                 ("mirror attribution", reina_model_amd/sharding.py) */
     uint32_t *work_counts;    /* [REINA_MAX_SCAN_WAVES] work items written by each scanning wave into
                                  its private slice of work_items (no global append counter) */
     uint32_t *sus_bits;       /* [ceil(N/32)] bit i set <=> agent i is SUSCEPTIBLE (never infected):
@@ -202,6 +220,13 @@ int reina_init_state(reina_engine_t *e, int32_t hospital_beds, int32_t icu_units
 int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t *t, void *stream);
 /* replaces Context.iterate() for one day (main.pyx:2011-2018) */
 int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream);
+/* the same day in two halves for a sharded population: `begin` runs everything up to and including
+ * contact sampling and leaves this shard's outgoing pressure in buffers.pressure; the caller sums
+ * `pressure` over all shards (ncclAllReduce / torch.distributed.all_reduce, the ONLY per-day
+ * collective); `end` realises the pressure aimed at this shard and installs the day's infections.
+ * reina_step_day == begin + end (with n_shards == 1 nothing is exchanged). */
+int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream);
+int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream);
 /* runs `n_days` consecutive days from an array of day descriptors (the loop of
  * calc/simulation.py:194-270 without the per-day host round trip) */
 int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, void *stream);

@@ -34,6 +34,9 @@ typedef struct {
     uint32_t thr[REINA_MAX_AGES][REINA_MAX_ENTRIES];
     uint32_t meta[REINA_MAX_AGES][REINA_MAX_ENTRIES];
     float mask_p[REINA_MAX_AGES][8];
+    uint32_t n_ranges;
+    int32_t range_min[REINA_MAX_RANGES], range_max[REINA_MAX_RANGES];
+    float psus_max[REINA_MAX_VARIANTS];
 } Par;
 
 #define CNT(e, c, age) ((e)->buf.counters[(c) * REINA_MAX_AGES + (age)])
@@ -66,8 +69,20 @@ int par_create(const reina_config_t *cfg, const reina_disease_t *disease, Par **
     Par *e = (Par *)calloc(1, sizeof(Par));
     e->cfg = *cfg;
     e->dis = *disease;
-    e->k0 = (uint32_t)cfg->seed;
-    e->k1 = (uint32_t)(cfg->seed >> 32);
+    if (e->cfg.n_shards == 0) e->cfg.n_shards = 1;
+    if (e->cfg.n_shards > REINA_MAX_SHARDS || e->cfg.shard_rank >= e->cfg.n_shards) {
+        free(e);
+        return REINA_E_INVALID;
+    }
+    uint64_t seed = rp_shard_seed(cfg->seed, e->cfg.shard_rank);
+    e->k0 = (uint32_t)seed;
+    e->k1 = (uint32_t)(seed >> 32);
+    for (uint32_t v = 0; v < cfg->nr_variants; v++) {
+        float m = 0.0f;
+        for (uint32_t a = 0; a < cfg->nr_ages; a++)
+            if (disease->p_susceptibility[v][a] > m) m = disease->p_susceptibility[v][a];
+        e->psus_max[v] = m;
+    }
     *out = e;
     return 0;
 }
@@ -96,6 +111,9 @@ int par_init_state(Par *e, int32_t beds, int32_t icu, void *stream) {
         e->buf.next_sibling[i] = -1;
         e->buf.claim[i] = ~0ull;
     }
+    if (e->cfg.n_shards > 1)
+        for (size_t k = 0; k < (size_t)REINA_MAX_RANGES * REINA_MAX_VARIANTS * e->cfg.mirror_slots; k++)
+            e->buf.mirror[k] = ~0ull;
     for (uint32_t k = 0; k < (N + 31) / 32 + 1; k++) e->buf.sus_bits[k] = 0;
     for (uint32_t i = 0; i < N; i++) e->buf.sus_bits[i >> 5] |= 1u << (i & 31);
     memset(e->buf.counters, 0, sizeof(int32_t) * REINA_COUNTER_WORDS);
@@ -116,6 +134,9 @@ int par_upload_contact_tables(Par *e, const reina_contact_tables_t *t, void *str
     memcpy(e->thr, t->threshold, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
     memcpy(e->meta, t->meta, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
     memcpy(e->mask_p, t->mask_p, sizeof(float) * A * 8);
+    e->n_ranges = t->n_ranges;
+    memcpy(e->range_min, t->range_min, sizeof(e->range_min));
+    memcpy(e->range_max, t->range_max, sizeof(e->range_max));
     return 0;
 }
 
@@ -614,11 +635,39 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
                 }
             uint32_t m = e->meta[row][ent];
             int place = (int)(m & 0xFF), cmin = (int)((m >> 8) & 0xFF), cmax = (int)((m >> 16) & 0xFF);
+            uint32_t range_id = m >> 24;
             uint32_t start = (uint32_t)e->cfg.age_start[cmin], end = (uint32_t)e->cfg.age_start[cmax + 1];
             SC(e, REINA_S_DAILY_CONTACTS + place) += 1;
             CTL(e, REINA_L_CONTACTS) += 1;
+            /* the contact is a uniform member of the age range over the WHOLE population: uniform
+             * shard, then uniform agent of that shard (every shard holds 1/G of every age) */
+            const uint32_t G = e->cfg.n_shards;
+            uint32_t dest = r.v[1] % G;
+            if (dest != e->cfg.shard_rank) {
+                /* source-side part of did_infect: everything that does not depend on the target;
+                 * the target's susceptibility is applied by the destination as p_sus / psus_max */
+                float q = src_inf * e->psus_max[v] * d->infectiousness_multiplier[v];
+                if (!rp_chance(q, r.v[2])) continue;
+                float mp = e->mask_p[row][place];
+                if (mp != 0.0f) {
+                    float a = mp * d->p_mask_protects_others[v];
+                    float b = mp * d->p_mask_protects_wearer[v];
+                    float pm = a + b - a * b;
+                    if (rp_chance(pm, r.v[3])) continue;
+                }
+                e->buf.pressure[(dest * REINA_MAX_RANGES + range_id) * REINA_MAX_VARIANTS + (uint32_t)v] += 1;
+                /* mirror table: keep the smallest (tie-break, src) per slot, tagged with today */
+                {
+                    rp_u4 hm = rp_philox(e->k0, e->k1, src, dp->day, RP_P_MIRROR, (uint32_t)c);
+                    uint32_t S = e->cfg.mirror_slots;
+                    uint64_t *slot = e->buf.mirror + ((size_t)(range_id * REINA_MAX_VARIANTS + (uint32_t)v)) * S + (hm.v[0] & (S - 1));
+                    uint64_t ent = rp_order_key(dp->day, hm.v[1] >> 12, src);
+                    if (ent < *slot) *slot = ent;
+                }
+                continue;
+            }
             if (end <= start) continue;
-            uint32_t t = start + r.v[1] % (end - start);
+            uint32_t t = start + (r.v[1] / G) % (end - start);
             if (!((e->buf.sus_bits[t >> 5] >> (t & 31)) & 1u)) continue;
             int age_t = age_of(e, t);
             float p = src_inf * d->p_susceptibility[v][age_t] * d->infectiousness_multiplier[v];
@@ -644,18 +693,76 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
     }
 }
 
+/* cross-shard pressure aimed at this shard (summed over all shards by the caller): attempt k of
+ * cell (range, variant) picks a uniform local agent of the range and passes the target-side part
+ * of did_infect, p_sus(age) / psus_max; it then competes for the target like a local contact */
+static void run_remote(Par *e, const reina_day_t *dp) {
+    const reina_disease_t *d = &e->dis;
+    if (e->cfg.n_shards <= 1) return;
+    uint32_t idx = 0;
+    for (uint32_t rg = 0; rg < e->n_ranges; rg++)
+        for (uint32_t v = 0; v < e->cfg.nr_variants; v++) {
+            int n = e->buf.pressure[(e->cfg.shard_rank * REINA_MAX_RANGES + rg) * REINA_MAX_VARIANTS + v];
+            uint32_t start = (uint32_t)e->cfg.age_start[e->range_min[rg]];
+            uint32_t end = (uint32_t)e->cfg.age_start[e->range_max[rg] + 1];
+            for (int k = 0; k < n; k++, idx++) {
+                if (end <= start) continue;
+                rp_u4 r = rp_philox(e->k0, e->k1, (uint32_t)k, dp->day, RP_P_REMOTE, rg | (v << 8));
+                uint32_t t = start + r.v[0] % (end - start);
+                if (!((e->buf.sus_bits[t >> 5] >> (t & 31)) & 1u)) continue;
+                int age_t = age_of(e, t);
+                float p = d->p_susceptibility[v][age_t] / e->psus_max[v];
+                if (!rp_chance(p, r.v[1])) continue;
+                uint32_t prio = r.v[2] >> 12;
+                /* mirror attribution: first slot at/after a hashed start holding an entry of today;
+                 * own cell first, then the other ranges of the variant, then the other variants */
+                uint32_t src = RP_REMOTE_SRC | idx;
+                {
+                    uint32_t S = e->cfg.mirror_slots;
+                    uint32_t probes = S < RP_MIRROR_PROBES ? S : RP_MIRROR_PROBES;
+                    int found = 0;
+                    for (uint32_t dv = 0; dv < e->cfg.nr_variants && !found; dv++)
+                        for (uint32_t dr = 0; dr < e->n_ranges && !found; dr++) {
+                            uint32_t cell = ((rg + dr) % e->n_ranges) * REINA_MAX_VARIANTS + (v + dv) % e->cfg.nr_variants;
+                            const uint64_t *tab = e->buf.mirror + (size_t)cell * S;
+                            for (uint32_t j = 0; j < probes; j++) {
+                                uint64_t ent = tab[(r.v[3] + j) & (S - 1)];
+                                if ((ent >> 52) == ((4095u - dp->day) & 0xFFFu)) {
+                                    src = (uint32_t)ent;
+                                    found = 1;
+                                    break;
+                                }
+                            }
+                        }
+                }
+                uint64_t key = rp_order_key(dp->day, prio, src);
+                if (key < e->buf.claim[t]) e->buf.claim[t] = key;
+                if ((uint32_t)CTL(e, REINA_L_CAND) >= e->cfg.max_candidates) {
+                    set_problem(e, REINA_PROBLEM_CANDIDATE_OVERFLOW);
+                    continue;
+                }
+                uint32_t *cd = e->buf.candidates + 4u * (uint32_t)CTL(e, REINA_L_CAND)++;
+                cd[0] = t;
+                cd[1] = src;
+                cd[2] = v;
+                cd[3] = prio;
+            }
+        }
+}
+
 static void run_install(Par *e, const reina_day_t *dp) {
     int C = CTL(e, REINA_L_CAND);
     for (int k = 0; k < C; k++) {
         const uint32_t *cd = e->buf.candidates + 4u * (uint32_t)k;
         if (e->buf.claim[cd[0]] != rp_order_key(dp->day, cd[3], cd[1])) continue;
         if (RH_STATE(e->buf.hot[cd[0]]) != RS_SUSCEPTIBLE) continue; /* duplicate record of the winner */
-        install_infection(e, cd[0], dp->day, cd[2], (int32_t)cd[1], 0, dp->testing_mode);
+        int32_t src = (cd[1] & RP_REMOTE_SRC) ? -1 : (int32_t)cd[1];
+        install_infection(e, cd[0], dp->day, cd[2], src, 0, dp->testing_mode);
     }
 }
 
-/* Context.iterate (main.pyx:2011-2018) in the parallel formulation */
-int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
+/* Context.iterate (main.pyx:2011-2018) in the parallel formulation, first half */
+int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
     (void)stream;
     if (!e->bound) return REINA_E_NOT_BOUND;
     if (dp->history_row) memcpy(dp->history_row, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
@@ -684,14 +791,28 @@ int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
     CTL(e, REINA_L_CONTACTS) = 0;
     CTL(e, REINA_L_HOSP_ADMIT) = 0;
     CTL(e, REINA_L_ICU_ADMIT) = 0;
+    memset(e->buf.pressure, 0, sizeof(int32_t) * REINA_PRESSURE_WORDS);
     run_imports(e, dp, 0, &import_base);
     run_testing(e, dp);
     run_vaccinations(e, dp);
     run_scan(e, dp);
     run_hospital(e, dp);
     run_contacts(e, dp);
+    return 0;
+}
+
+/* second half: after the caller has summed `pressure` over the shards */
+int par_step_day_end(Par *e, const reina_day_t *dp, void *stream) {
+    (void)stream;
+    run_remote(e, dp);
     run_install(e, dp);
     return 0;
+}
+
+int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
+    int rc = par_step_day_begin(e, dp, stream);
+    if (rc) return rc;
+    return par_step_day_end(e, dp, stream);
 }
 
 int par_run_days(Par *e, const reina_day_t *days, uint32_t n, void *stream) {

@@ -46,6 +46,11 @@ struct DevParams {
     float nrc[REINA_MAX_AGES];
     int32_t tcount[REINA_MAX_AGES];
     float mask_p[REINA_MAX_AGES][8];
+    // sharding
+    uint32_t n_shards, shard_rank, mirror_slots;
+    float psus_max[REINA_MAX_VARIANTS];
+    uint32_t n_ranges;
+    int32_t range_min[REINA_MAX_RANGES], range_max[REINA_MAX_RANGES];
 };
 
 struct Tables {  // bigger tables staged into LDS by k_contacts
@@ -70,6 +75,7 @@ struct reina_engine {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<size_t, size_t>> scan_pairs, day_pairs;
+    size_t ev_day0 = 0;
     double scan_ms = 0, all_ms = 0;
     uint64_t scan_launches = 0;
 };
@@ -228,6 +234,10 @@ __global__ void k_init(const DevParams *P, reina_buffers_t B, int32_t beds, int3
         B.first_infectee[i] = -1;
         B.next_sibling[i] = -1;
         B.claim[i] = ~0ull;
+    }
+    if (P->n_shards > 1) {
+        const size_t nm = (size_t)REINA_MAX_RANGES * REINA_MAX_VARIANTS * P->mirror_slots;
+        for (size_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nm; k += stride) B.mirror[k] = ~0ull;
     }
     const uint32_t nwords = (N + 31u) / 32u + 1u;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nwords; k += stride) {
@@ -439,6 +449,7 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
         B.counters[CNT_IDX(REINA_C_NEW_INFECTIONS, k)] = 0;
         B.counters[CNT_IDX(REINA_C_DETECTED, k)] = 0;
     }
+    for (int k = tid; k < REINA_PRESSURE_WORDS; k += PRO_THREADS) B.pressure[k] = 0;
     if (tid < REINA_NR_PLACES) B.counters[SC_IDX(REINA_S_DAILY_CONTACTS + tid)] = 0;
     if (tid < REINA_MAX_VARIANTS) B.counters[SC_IDX(REINA_S_INFECTED_BY_VARIANT + tid)] = 0;
     if (tid == 0) {
@@ -1132,7 +1143,6 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
 #define CAND_CHUNK 128
 
 struct ConShared {
-    uint32_t thr[REINA_MAX_AGES][REINA_MAX_ENTRIES];
     uint32_t meta_row[REINA_MAX_ENTRIES];   // shared (place, range) pattern when every age has the same
     float mask_p[REINA_MAX_AGES][8];
     float p_sus[REINA_MAX_VARIANTS][REINA_MAX_AGES];
@@ -1142,17 +1152,24 @@ struct ConShared {
     uint4 item[CON_WAVES][64];          // the wave's current 64 work items
     int32_t daily[REINA_NR_PLACES];
     int32_t n_contacts;
+    // dynamic tail: uint32_t thr[nr_ages][REINA_MAX_ENTRIES]; then, when sharded,
+    // int32_t pressure[REINA_PRESSURE_WORDS] (this workgroup's outgoing cross-shard pressure)
 };
+static size_t con_shared_bytes(uint32_t nr_ages, uint32_t n_shards) {
+    return sizeof(ConShared) + (size_t)nr_ages * REINA_MAX_ENTRIES * 4 + (n_shards > 1 ? REINA_PRESSURE_WORDS * 4 : 0);
+}
 
 __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, const Tables *T, reina_buffers_t B, reina_day_t dp,
                                                           uint32_t scan_waves, uint32_t scan_tiles, int uniform_meta) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     ConShared &S = *reinterpret_cast<ConShared *>(smem_raw);
+    uint32_t (*S_thr)[REINA_MAX_ENTRIES] = reinterpret_cast<uint32_t (*)[REINA_MAX_ENTRIES]>(smem_raw + sizeof(ConShared));
+    int32_t *S_pressure = reinterpret_cast<int32_t *>(smem_raw + sizeof(ConShared) + (size_t)P->nr_ages * REINA_MAX_ENTRIES * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.x * CON_WAVES >= scan_waves) return;  // no slice for this workgroup
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&T->thr[0][0]);
-        uint4 *dst = reinterpret_cast<uint4 *>(&S.thr[0][0]);
+        uint4 *dst = reinterpret_cast<uint4 *>(&S_thr[0][0]);
         const int n16 = (int)(P->nr_ages * REINA_MAX_ENTRIES * 4 / 16);
         for (int k = tid; k < n16; k += CON_THREADS) dst[k] = src[k];
         if (tid < REINA_MAX_ENTRIES) S.meta_row[tid] = T->meta[0][tid];
@@ -1162,9 +1179,12 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
         for (int k = tid; k < REINA_MAX_AGES; k += CON_THREADS) S.tcount[k] = P->tcount[k];
         if (tid < REINA_NR_PLACES) S.daily[tid] = 0;
         if (tid == 0) S.n_contacts = 0;
+        if (P->n_shards > 1)
+            for (int k = tid; k < REINA_PRESSURE_WORDS; k += CON_THREADS) S_pressure[k] = 0;
     }
     __syncthreads();
     const reina_disease_t &d = P->dis;
+    const uint32_t n_shards = P->n_shards, shard_rank = P->shard_rank;
     const uint4 *items = reinterpret_cast<const uint4 *>(B.work_items);
     const uint32_t total_waves = gridDim.x * CON_WAVES;
     const uint32_t tq = scan_tiles / scan_waves, tr = scan_tiles % scan_waves;
@@ -1217,14 +1237,38 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
                     int l2 = 0, h2 = cnt - 1;
                     while (l2 < h2) {
                         int mid = (l2 + h2) >> 1;
-                        if (r.v[0] < S.thr[row][mid]) h2 = mid; else l2 = mid + 1;
+                        if (r.v[0] < S_thr[row][mid]) h2 = mid; else l2 = mid + 1;
                     }
                     const uint32_t m = uniform_meta ? S.meta_row[l2] : T->meta[row][l2];
                     place = (int)(m & 0xFFu);
                     const int cmin = (int)((m >> 8) & 0xFFu), cmax = (int)((m >> 16) & 0xFFu);
                     const uint32_t start = (uint32_t)S.age_start[cmin], end = (uint32_t)S.age_start[cmax + 1];
-                    if (end > start) {
-                        const uint32_t t = start + r.v[1] % (end - start);
+                    // uniform member of the range over the WHOLE population: uniform shard, then
+                    // uniform agent of that shard (every shard holds 1/G of every age)
+                    const uint32_t dest = r.v[1] % n_shards;
+                    if (dest != shard_rank) {
+                        // source-side part of did_infect; the destination applies p_sus / psus_max
+                        float qv = src_inf * P->psus_max[v] * d.infectiousness_multiplier[v];
+                        bool pass = rp_chance(qv, r.v[2]) != 0;
+                        if (pass) {
+                            const float mp = S.mask_p[row][place];
+                            if (mp != 0.0f) {
+                                float a = mp * d.p_mask_protects_others[v];
+                                float b = mp * d.p_mask_protects_wearer[v];
+                                float pm = a + b - a * b;
+                                if (rp_chance(pm, r.v[3])) pass = false;
+                            }
+                        }
+                        if (pass) {
+                            atomicAdd(&S_pressure[(dest * REINA_MAX_RANGES + (m >> 24)) * REINA_MAX_VARIANTS + (uint32_t)v], 1);
+                            // mirror table: smallest (tie-break, src) per slot, tagged with today
+                            rp_u4 hm = rp_philox(P->k0, P->k1, src, dp.day, RP_P_MIRROR, c);
+                            const uint32_t MS = P->mirror_slots;
+                            uint64_t *slot = B.mirror + ((size_t)((m >> 24) * REINA_MAX_VARIANTS + (uint32_t)v)) * MS + (hm.v[0] & (MS - 1));
+                            atomicMin((unsigned long long *)slot, (unsigned long long)rp_order_key(dp.day, hm.v[1] >> 12, src));
+                        }
+                    } else if (end > start) {
+                        const uint32_t t = start + (r.v[1] / n_shards) % (end - start);
                         // 1 bit per agent: the whole table (N/8 bytes) stays in L2 / Infinity Cache
                         if ((B.sus_bits[t >> 5] >> (t & 31u)) & 1u) {
                             const int age_t = age_of(S.age_start, t, cmin, cmax);
@@ -1290,6 +1334,80 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
     __syncthreads();
     if (tid < REINA_NR_PLACES && S.daily[tid]) atomicAdd(&B.counters[SC_IDX(REINA_S_DAILY_CONTACTS + tid)], S.daily[tid]);
     if (tid == 0 && S.n_contacts) atomicAdd(&B.control[REINA_L_CONTACTS], S.n_contacts);
+    if (n_shards > 1)
+        for (int k = tid; k < REINA_PRESSURE_WORDS; k += CON_THREADS)
+            if (S_pressure[k]) atomicAdd(&B.pressure[k], S_pressure[k]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_remote: realise the cross-shard infection pressure aimed at this shard (buffers.pressure has
+// been summed over all shards by the caller).  Attempt k of cell (range, variant) picks a uniform
+// local agent of the range and applies the target-side part of did_infect, p_sus(age)/psus_max;
+// survivors compete for the target exactly like local contacts (atomicMin claim + candidate).
+__global__ __launch_bounds__(256) void k_remote(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
+    __shared__ uint32_t s_pre[REINA_MAX_RANGES * REINA_MAX_VARIANTS + 1];  // exclusive prefix of cell counts
+    const int tid = threadIdx.x;
+    const uint32_t V = P->nr_variants, cells = P->n_ranges * V;
+    if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t c = 0; c < cells; c++) {
+            s_pre[c] = acc;
+            uint32_t rg = c / V, v = c % V;
+            int n = B.pressure[(P->shard_rank * REINA_MAX_RANGES + rg) * REINA_MAX_VARIANTS + v];
+            acc += n > 0 ? (uint32_t)n : 0u;
+        }
+        s_pre[cells] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = s_pre[cells];
+    const reina_disease_t &d = P->dis;
+    for (uint32_t idx = blockIdx.x * blockDim.x + tid; idx < total; idx += gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = cells - 1;  // cell with s_pre[cell] <= idx < s_pre[cell+1]
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (s_pre[mid] <= idx) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t rg = lo / V, v = lo % V, k = idx - s_pre[lo];
+        const uint32_t start = (uint32_t)s_age_start[P->range_min[rg]], end = (uint32_t)s_age_start[P->range_max[rg] + 1];
+        if (end <= start) continue;
+        rp_u4 r = rp_philox(P->k0, P->k1, k, dp.day, RP_P_REMOTE, rg | (v << 8));
+        const uint32_t t = start + r.v[0] % (end - start);
+        if (!((B.sus_bits[t >> 5] >> (t & 31u)) & 1u)) continue;
+        const int age_t = age_of(s_age_start, t, P->range_min[rg], P->range_max[rg]);
+        const float p = d.p_susceptibility[v][age_t] / P->psus_max[v];
+        if (!rp_chance(p, r.v[1])) continue;
+        const uint32_t prio = r.v[2] >> 12;
+        // mirror attribution: first slot at/after a hashed start that holds an entry of today;
+        // own cell first, then the other ranges of the variant, then the other variants
+        uint32_t src = RP_REMOTE_SRC | idx;
+        {
+            const uint32_t MS = P->mirror_slots;
+            const uint32_t probes = MS < RP_MIRROR_PROBES ? MS : RP_MIRROR_PROBES;
+            bool found = false;
+            for (uint32_t dv = 0; dv < V && !found; dv++)
+                for (uint32_t dr = 0; dr < P->n_ranges && !found; dr++) {
+                    const uint32_t cell = ((rg + dr) % P->n_ranges) * REINA_MAX_VARIANTS + (v + dv) % V;
+                    const uint64_t *tab = B.mirror + (size_t)cell * MS;
+                    for (uint32_t j = 0; j < probes; j++) {
+                        uint64_t ent = tab[(r.v[3] + j) & (MS - 1)];
+                        if ((ent >> 52) == ((4095u - dp.day) & 0xFFFu)) {
+                            src = (uint32_t)ent;
+                            found = true;
+                            break;
+                        }
+                    }
+                }
+        }
+        atomicMin((unsigned long long *)&B.claim[t], (unsigned long long)rp_order_key(dp.day, prio, src));
+        uint32_t pos = wave_alloc(&B.control[REINA_L_CAND]);
+        if (pos >= P->max_candidates) {
+            set_problem(B.counters, REINA_PROBLEM_CANDIDATE_OVERFLOW);
+            continue;
+        }
+        reinterpret_cast<uint4 *>(B.candidates)[pos] = make_uint4(t, src, v, prio);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1312,7 +1430,8 @@ __global__ void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp)
         if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
         uint32_t w = ld_hot(&B.hot[cd.x]);
         if (RH_STATE(w) != RS_SUSCEPTIBLE) continue;  // duplicate record of the same winner
-        install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode, new_by_age, new_by_variant);
+        const int32_t src = (cd.y & RP_REMOTE_SRC) ? -1 : (int32_t)cd.y;
+        install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, src, 0, dp.testing_mode, new_by_age, new_by_variant);
     }
     flush_new_infections(B, new_by_age, new_by_variant, (int)blockDim.x);
 }
@@ -1380,8 +1499,29 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     e->h_params.n_agents = cfg->n_agents;
     e->h_params.nr_ages = cfg->nr_ages;
     e->h_params.nr_variants = cfg->nr_variants;
-    e->h_params.k0 = (uint32_t)cfg->seed;
-    e->h_params.k1 = (uint32_t)(cfg->seed >> 32);
+    e->cfg.n_shards = cfg->n_shards ? cfg->n_shards : 1;
+    if (e->cfg.n_shards > REINA_MAX_SHARDS || e->cfg.shard_rank >= e->cfg.n_shards) {
+        g_last_error = "n_shards / shard_rank out of range";
+        delete e;
+        return REINA_E_INVALID;
+    }
+    const uint64_t shard_seed = rp_shard_seed(cfg->seed, e->cfg.shard_rank);
+    e->h_params.k0 = (uint32_t)shard_seed;
+    e->h_params.k1 = (uint32_t)(shard_seed >> 32);
+    e->h_params.n_shards = e->cfg.n_shards;
+    e->h_params.shard_rank = e->cfg.shard_rank;
+    e->h_params.mirror_slots = cfg->mirror_slots ? cfg->mirror_slots : 64;
+    if (e->h_params.mirror_slots & (e->h_params.mirror_slots - 1)) {
+        g_last_error = "mirror_slots must be a power of two";
+        delete e;
+        return REINA_E_INVALID;
+    }
+    for (uint32_t v = 0; v < cfg->nr_variants; v++) {
+        float m = 0.0f;
+        for (uint32_t a = 0; a < cfg->nr_ages; a++)
+            if (disease->p_susceptibility[v][a] > m) m = disease->p_susceptibility[v][a];
+        e->h_params.psus_max[v] = m;
+    }
     e->h_params.max_work_items = cfg->max_work_items;
     e->h_params.max_candidates = cfg->max_candidates;
     e->h_params.max_queue = cfg->max_queue;
@@ -1390,7 +1530,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)sizeof(ConShared)));
+                                  (int)con_shared_bytes(REINA_MAX_AGES, REINA_MAX_SHARDS)));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hospital), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(REINA_MAX_HOSP_EVENTS * 8)));
     *out = e;
@@ -1434,6 +1574,9 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     std::memcpy(e->h_params.nrc, t->nr_contacts_by_age, sizeof(float) * A);
     std::memcpy(e->h_params.tcount, t->count, sizeof(int32_t) * A);
     std::memcpy(e->h_params.mask_p, t->mask_p, sizeof(float) * A * 8);
+    e->h_params.n_ranges = t->n_ranges;
+    std::memcpy(e->h_params.range_min, t->range_min, sizeof(t->range_min));
+    std::memcpy(e->h_params.range_max, t->range_max, sizeof(t->range_max));
     std::memcpy(e->h_tables.thr, t->threshold, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
     std::memcpy(e->h_tables.meta, t->meta, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
     e->uniform_meta = 1;  // every participant age lists the same (place, contact range) sequence?
@@ -1448,7 +1591,7 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     return REINA_OK;
 }
 
-int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
+int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream) {
     if (!e || !day) return REINA_E_INVALID;
     if (!e->bound) return REINA_E_NOT_BOUND;
     hipStream_t s = (hipStream_t)stream;
@@ -1490,17 +1633,36 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
     {
         uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
         if (con_blocks > 512) con_blocks = 512;
-        hipLaunchKernelGGL(k_contacts, dim3(con_blocks), dim3(CON_THREADS), sizeof(ConShared), s,
+        hipLaunchKernelGGL(k_contacts, dim3(con_blocks), dim3(CON_THREADS), con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards), s,
                            e->d_params, e->d_tables, e->buf, dp, scan_waves, scan_tiles, e->uniform_meta);
     }
+    e->ev_day0 = ev_day0;
+    HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+
+int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) {
+    if (!e || !day) return REINA_E_INVALID;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    hipStream_t s = (hipStream_t)stream;
+    const reina_day_t dp = *day;
+    const uint32_t N = e->cfg.n_agents;
+    if (e->cfg.n_shards > 1)
+        hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256)), dim3(256), 0, s, e->d_params, e->buf, dp);
     hipLaunchKernelGGL(k_install, dim3(grid_for(N / 64 + 1, 256, 512)), dim3(256), 0, s, e->d_params, e->buf, dp);
     if (e->profile) {
         size_t ev_day1 = take_event(e);
         hipEventRecord(e->ev_pool[ev_day1], s);
-        e->day_pairs.emplace_back(ev_day0, ev_day1);
+        e->day_pairs.emplace_back(e->ev_day0, ev_day1);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
+}
+
+int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
+    int rc = reina_step_day_begin(e, day, stream);
+    if (rc) return rc;
+    return reina_step_day_end(e, day, stream);
 }
 
 int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, void *stream) {

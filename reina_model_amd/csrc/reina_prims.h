@@ -70,7 +70,9 @@ enum {
     RP_P_HOSPITAL = 5,    // (agent, day): no-bed / no-ICU death roll
     RP_P_TRACE = 6,       // (candidate, day, c3 = tracer): contact-tracing success
     RP_P_IMPORT = 7,      // (import #, day, c3 = try): age class, target
-    RP_P_PRIORITY = 8     // (agent, day): order key for scarce resources / winner selection
+    RP_P_PRIORITY = 8,    // (agent, day): order key for scarce resources / winner selection
+    RP_P_REMOTE = 9,      // (attempt #, day, c3 = range | variant << 8): realisation of cross-shard pressure
+    RP_P_MIRROR = 10      // (agent, day, c3 = contact #): slot + tie-break of an outgoing attempt in the mirror table
 };
 
 // uniform in [0,1) with 24 random bits: exact in float
@@ -241,5 +243,13 @@ RP_HD uint64_t rp_order_key(uint32_t day, uint32_t prio20, uint32_t id) {
 RP_HD uint32_t rp_priority20(uint32_t k0, uint32_t k1, uint32_t who, uint32_t day) {
     return rp_philox(k0, k1, who, day, RP_P_PRIORITY, 0).v[0] >> 12;
 }
+
+// Sharded populations: every shard derives its own Philox key from the common seed.
+RP_HD uint64_t rp_shard_seed(uint64_t seed, uint32_t rank) {
+    return seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;
+}
+// candidate "source id" of an infection realised from cross-shard pressure (no local infector)
+#define RP_REMOTE_SRC 0x80000000u
+#define RP_MIRROR_PROBES 1024u
 
 #endif  // REINA_PRIMS_H

@@ -27,6 +27,9 @@ MAX_IMPORT_BATCHES = 16
 MAX_VACCINATIONS = 16
 MAX_HOSP_EVENTS = 16384
 MAX_SCAN_WAVES = 8192
+MAX_SHARDS = 16
+MAX_RANGES = 32
+PRESSURE_WORDS = MAX_SHARDS * MAX_RANGES * MAX_VARIANTS
 
 C_NAMES = ('infected', 'detected', 'all_detected', 'all_infected', 'in_ward', 'hospitalized',
            'in_icu', 'cum_icu', 'dead', 'susceptible', 'recovered', 'vaccinated',
@@ -41,7 +44,7 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 32
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'upload_contact_tables',
-                 'step_day', 'run_days', 'read_counters', 'profile_enable', 'profile_read',
+                 'step_day', 'step_day_begin', 'step_day_end', 'run_days', 'read_counters', 'profile_enable', 'profile_read',
                  'last_error', 'abi_version')
 
 
@@ -50,7 +53,8 @@ class Config(ctypes.Structure):
                 ('nr_variants', ctypes.c_uint32), ('reserved0', ctypes.c_uint32),
                 ('seed', ctypes.c_uint64),
                 ('max_work_items', ctypes.c_uint32), ('max_candidates', ctypes.c_uint32),
-                ('max_queue', ctypes.c_uint32), ('reserved1', ctypes.c_uint32),
+                ('max_queue', ctypes.c_uint32), ('n_shards', ctypes.c_uint32),
+                ('shard_rank', ctypes.c_uint32), ('mirror_slots', ctypes.c_uint32),
                 ('age_start', ctypes.c_int32 * (MAX_AGES + 1))]
 
 
@@ -78,12 +82,13 @@ class Disease(ctypes.Structure):
 class ContactTablesABI(ctypes.Structure):
     _fields_ = [('nr_contacts_by_age', ctypes.c_void_p), ('count', ctypes.c_void_p),
                 ('threshold', ctypes.c_void_p), ('meta', ctypes.c_void_p),
-                ('mask_p', ctypes.c_void_p)]
+                ('mask_p', ctypes.c_void_p), ('n_ranges', ctypes.c_uint32),
+                ('range_min', ctypes.c_int32 * MAX_RANGES), ('range_max', ctypes.c_int32 * MAX_RANGES)]
 
 
 BUFFER_FIELDS = ('hot', 'infector', 'n_infected', 'onset_days', 'vacc_day', 'first_infectee',
                  'next_sibling', 'claim', 'counters', 'control', 'work_items', 'candidates',
-                 'queue0', 'queue1', 'level1', 'hosp_events', 'work_counts', 'sus_bits')
+                 'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'work_counts', 'sus_bits')
 
 
 class Buffers(ctypes.Structure):
@@ -122,6 +127,8 @@ def bind_abi(lib, prefix):
     f['init_state'].argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp]
     f['upload_contact_tables'].argtypes = [vp, ctypes.POINTER(ContactTablesABI), vp]
     f['step_day'].argtypes = [vp, ctypes.POINTER(Day), vp]
+    f['step_day_begin'].argtypes = [vp, ctypes.POINTER(Day), vp]
+    f['step_day_end'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp]
     f['read_counters'].argtypes = [vp, vp, vp]
     f['profile_enable'].argtypes = [vp, ctypes.c_int]
@@ -204,6 +211,8 @@ class Engine:
             candidates=a.zeros(4 * config.max_candidates, np.uint32),
             queue0=a.zeros(config.max_queue, np.uint32), queue1=a.zeros(config.max_queue, np.uint32),
             level1=a.zeros(config.max_queue, np.uint32), hosp_events=a.zeros(MAX_HOSP_EVENTS, np.uint64),
+            pressure=a.zeros(PRESSURE_WORDS, np.int32),
+            mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 8, np.uint64),
             work_counts=a.zeros(MAX_SCAN_WAVES, np.uint32),
             sus_bits=a.zeros((n + 31) // 32 + 1, np.uint32),
         )
@@ -230,15 +239,25 @@ class Engine:
     def init_state(self, beds, icu_units):
         self._check(self.f['init_state'](self._h, int(beds), int(icu_units), self.alloc.stream()), 'init_state')
 
-    def upload_contact_tables(self, nrc, count, threshold, meta, mask_p):
+    def upload_contact_tables(self, nrc, count, threshold, meta, mask_p, ranges):
         arrs = [np.ascontiguousarray(nrc, dtype=np.float32), np.ascontiguousarray(count, dtype=np.int32),
                 np.ascontiguousarray(threshold, dtype=np.uint32), np.ascontiguousarray(meta, dtype=np.uint32),
                 np.ascontiguousarray(mask_p, dtype=np.float32)]
         t = ContactTablesABI(*[x.ctypes.data for x in arrs])
+        t.n_ranges = len(ranges)
+        for k, (lo, hi) in enumerate(ranges):
+            t.range_min[k] = int(lo)
+            t.range_max[k] = int(hi)
         self._check(self.f['upload_contact_tables'](self._h, ctypes.byref(t), self.alloc.stream()), 'upload_contact_tables')
 
     def step_day(self, day):
         self._check(self.f['step_day'](self._h, ctypes.byref(day), self.alloc.stream()), 'step_day')
+
+    def step_day_begin(self, day):
+        self._check(self.f['step_day_begin'](self._h, ctypes.byref(day), self.alloc.stream()), 'step_day_begin')
+
+    def step_day_end(self, day):
+        self._check(self.f['step_day_end'](self._h, ctypes.byref(day), self.alloc.stream()), 'step_day_end')
 
     def run_days(self, days):
         arr = (Day * len(days))(*days)

@@ -147,6 +147,11 @@ def pack_contact_tables(tables, nr_ages):
     count = np.zeros(_eng.MAX_AGES, dtype=np.int32)
     thr = np.full((_eng.MAX_AGES, E), 0xFFFFFFFF, dtype=np.uint32)
     meta = np.zeros((_eng.MAX_AGES, E), dtype=np.uint32)
+    ranges = sorted(set(zip(tables.cmin.tolist(), tables.cmax.tolist())))
+    if len(ranges) > _eng.MAX_RANGES:
+        raise ValueError('more than %d distinct contact age ranges' % _eng.MAX_RANGES)
+    range_id = {r: k for k, r in enumerate(ranges)}
+    rid = np.asarray([range_id[r] for r in zip(tables.cmin.tolist(), tables.cmax.tolist())], dtype=np.uint32)
     for a in range(nr_ages):
         o, c = int(tables.offset[a]), int(tables.count[a])
         if c > E:
@@ -158,15 +163,24 @@ def pack_contact_tables(tables, nr_ages):
         thr[a, :c] = np.clip(t, 0, 4294967295.0).astype(np.uint64).astype(np.uint32)
         meta[a, :c] = (tables.place[o:o + c].astype(np.uint32)
                        | (tables.cmin[o:o + c].astype(np.uint32) << 8)
-                       | (tables.cmax[o:o + c].astype(np.uint32) << 16))
-    return nrc, count, thr, meta
+                       | (tables.cmax[o:o + c].astype(np.uint32) << 16)
+                       | (rid[o:o + c] << 24))
+    return nrc, count, thr, meta, ranges
 
 
 class Context:
     """MI355X-native agent engine with the reference `Context` protocol (main.pyx:1746-2101)."""
 
     def __init__(self, population_params, healthcare_params, disease_params, start_date,
-                 random_seed=4321, device='cuda:0', engine_factory=None):
+                 random_seed=4321, device='cuda:0', engine_factory=None, comm=None):
+        """`comm` (sharding.TorchComm or compatible: .rank, .world, .all_reduce_sum/max) makes this
+        Context one shard of a population split over comm.world engine instances; population,
+        beds, ICU units and import / vaccination quotas given here are the GLOBAL ones."""
+        from .sharding import split_count, split_population
+        self.comm = comm
+        self.shard_rank = comm.rank if comm is not None else 0
+        self.n_shards = comm.world if comm is not None else 1
+        self._split = lambda x: split_count(x, self.shard_rank, self.n_shards)
         population_params = dict(population_params)
         ipc = population_params.pop('initial_population_condition', None)
         if ipc is not None and hasattr(ipc, 'has_initial_state') and ipc.has_initial_state():
@@ -183,6 +197,11 @@ class Context:
             nr_ages = len(age_counts)
         if nr_ages > _eng.MAX_AGES:
             raise ValueError('at most %d ages' % _eng.MAX_AGES)
+        self.global_age_counts = age_counts.copy()
+        if self.n_shards > 1:
+            if self.n_shards > _eng.MAX_SHARDS:
+                raise ValueError('at most %d shards' % _eng.MAX_SHARDS)
+            age_counts = split_population(age_counts, self.shard_rank, self.n_shards)
         total = int(age_counts.sum())
         if total >= 2 ** 31:
             raise ValueError('a single engine instance holds < 2^31 agents; shard the population')
@@ -208,6 +227,12 @@ class Context:
         cfg.max_work_items = total + 1024
         cfg.max_candidates = total + 1024 * 1024
         cfg.max_queue = total + 64
+        cfg.n_shards = self.n_shards
+        cfg.shard_rank = self.shard_rank
+        slots = 64
+        while slots < total // 1024 and slots < (1 << 20):
+            slots <<= 1
+        cfg.mirror_slots = slots
         for a in range(_eng.MAX_AGES + 1):
             cfg.age_start[a] = int(self.age_start[a])
         if engine_factory is None:
@@ -216,7 +241,7 @@ class Context:
             self.engine = engine_factory(cfg, disease)
         self.beds = int(healthcare_params['hospital_beds'])
         self.icu_units = int(healthcare_params['icu_units'])
-        self.engine.init_state(self.beds, self.icu_units)
+        self.engine.init_state(self._split(self.beds), self._split(self.icu_units))
 
         self.contact_matrix = ContactMatrix(population_params['contacts_per_day'], nr_ages)
         self._upload_tables()
@@ -243,10 +268,10 @@ class Context:
     # ------------------------------------------------------------------ host helpers
     def _upload_tables(self):
         t = self.contact_matrix.tables
-        nrc, count, thr, meta = pack_contact_tables(t, self.nr_ages)
+        nrc, count, thr, meta, ranges = pack_contact_tables(t, self.nr_ages)
         mask = np.zeros((_eng.MAX_AGES, 8), dtype=np.float32)
         mask[:self.nr_ages, :6] = self.contact_matrix.mask_probabilities.astype(np.float32)
-        self.engine.upload_contact_tables(nrc, count, thr, meta, mask)
+        self.engine.upload_contact_tables(nrc, count, thr, meta, mask, ranges)
 
     def get_date_for_today(self):
         d = date.fromisoformat(self.start_date)
@@ -345,8 +370,9 @@ class Context:
         d.testing_mode = self.testing_mode
         d.p_detected_anyway = float(self.p_detected_anyway)
         d.p_successful_tracing = float(self.p_successful_tracing)
-        d.add_beds = self._pending_beds
-        d.add_icu_units = self._pending_icu
+        # quotas are global; a shard takes its 1/G share (new capacity: of the running totals)
+        d.add_beds = self._split(self.beds + self._pending_beds) - self._split(self.beds)
+        d.add_icu_units = self._split(self.icu_units + self._pending_icu) - self._split(self.icu_units)
         self.beds += self._pending_beds
         self.icu_units += self._pending_icu
         self._pending_beds = 0
@@ -357,7 +383,7 @@ class Context:
             raise Exception('more than %d import batches in one day' % _eng.MAX_IMPORT_BATCHES)
         d.n_import_batches = len(batches)
         for k, (count, variant, pre) in enumerate(batches):
-            d.import_batches[k].count = count
+            d.import_batches[k].count = self._split(count)
             d.import_batches[k].variant = variant
             d.import_batches[k].pre_init = pre
         nv = 0
@@ -367,7 +393,7 @@ class Context:
                 continue
             mn = 0 if v['min_age'] is None else v['min_age']
             mx = pop_max_age if v['max_age'] is None else v['max_age']
-            d.vaccinations[nv].nr = int(v['nr_daily'])
+            d.vaccinations[nv].nr = self._split(int(v['nr_daily']))
             d.vaccinations[nv].idx_start = int(self.age_start[mn])
             d.vaccinations[nv].idx_end = int(self.age_start[mx + 1]) if mx < pop_max_age else self.total_people
             d.vaccinations[nv].slot = v['slot']
@@ -378,11 +404,20 @@ class Context:
 
     # ------------------------------------------------------------------ day stepping
     # main.pyx:2011-2018
+    def _step(self, d):
+        if self.n_shards == 1:
+            self.engine.step_day(d)
+        else:
+            # the ONLY per-day collective: sum the cross-shard infection pressure (2048 int32)
+            self.engine.step_day_begin(d)
+            self.comm.all_reduce_sum(self.engine.tensors['pressure'])
+            self.engine.step_day_end(d)
+
     def iterate(self):
         d, changed = self._build_day()
         if changed:
             self._upload_tables()
-        self.engine.step_day(d)
+        self._step(d)
         self.day += 1
 
     def run(self, days, record_history=True):
@@ -405,18 +440,53 @@ class Context:
                     self.engine.run_days(pending)
                     pending = []
                 self._upload_tables()
-            pending.append(d)
+            if self.n_shards == 1:
+                pending.append(d)
+            else:
+                self._step(d)
             self.day += 1
         if pending:
             self.engine.run_days(pending)
         if record_history:
-            out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
-            self._raise_on_problem(self.engine.read_counters())
+            if self.n_shards > 1:
+                out = self._reduce_counter_rows(hist, days)
+            else:
+                out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
+            self._raise_on_problem(self._read_counters_global())
             return out
         return None
 
+    # ---- sharded state export: counters are additive over shards; problem / day are not
+    def _reduce_counter_rows(self, buf, rows):
+        base = _eng.C_NR * _eng.MAX_AGES
+        local = self.engine.alloc.to_host(buf).reshape(rows, _eng.COUNTER_WORDS).copy()
+        problem = np.ascontiguousarray(local[:, base + _eng.S_PROBLEM])
+        day = local[:, base + _eng.S_DAY].copy()
+        self.comm.all_reduce_sum(local)
+        self.comm.all_reduce_max(problem)
+        local[:, base + _eng.S_PROBLEM] = problem
+        local[:, base + _eng.S_DAY] = day
+        return local
+
+    def _read_counters_global(self):
+        c = self.engine.read_counters()
+        if self.n_shards == 1:
+            return c
+        return self._reduce_counter_rows_host(c)
+
+    def _reduce_counter_rows_host(self, c):
+        base = _eng.C_NR * _eng.MAX_AGES
+        local = np.array(c, dtype=np.int32).reshape(1, -1)
+        problem = np.ascontiguousarray(local[:, base + _eng.S_PROBLEM])
+        day = local[:, base + _eng.S_DAY].copy()
+        self.comm.all_reduce_sum(local)
+        self.comm.all_reduce_max(problem)
+        local[:, base + _eng.S_PROBLEM] = problem
+        local[:, base + _eng.S_DAY] = day
+        return local[0]
+
     def synchronize(self):
-        self._raise_on_problem(self.engine.read_counters())
+        self._raise_on_problem(self._read_counters_global())
 
     def _raise_on_problem(self, counters):
         problem = int(counters[_eng.C_NR * _eng.MAX_AGES + _eng.S_PROBLEM])
@@ -452,7 +522,7 @@ class Context:
         return s
 
     def generate_state(self):
-        counters = self.engine.read_counters()
+        counters = self._read_counters_global()
         self._raise_on_problem(counters)
         return self.state_from_counters(counters)
 
@@ -460,11 +530,11 @@ class Context:
     def get_population_stats(self, what):
         if what not in ('dead', 'all_infected', 'all_detected'):
             raise Exception()
-        counters = self.engine.read_counters()
+        counters = self._read_counters_global()
         ci = _eng.C_NAMES.index(what)
         return counters[ci * _eng.MAX_AGES: ci * _eng.MAX_AGES + self.nr_ages].copy()
 
     def per_age_counters(self):
-        counters = self.engine.read_counters()
+        counters = self._read_counters_global()
         return {n: counters[i * _eng.MAX_AGES: i * _eng.MAX_AGES + self.nr_ages].copy()
                 for i, n in enumerate(_eng.C_NAMES)}

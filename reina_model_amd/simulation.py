@@ -48,7 +48,7 @@ def create_disease_params(variables):
 
 
 def make_context(variables, age_counts=None, seed=None, interventions=None, device='cuda:0',
-                 engine_factory=None):
+                 engine_factory=None, comm=None):
     """Build a Context the way calc/simulation.py:148-180 does."""
     if age_counts is None:
         age_counts = datasets.get_population_for_area(variables['area_name'])
@@ -64,7 +64,7 @@ def make_context(variables, age_counts=None, seed=None, interventions=None, devi
     hc = dict(hospital_beds=variables['hospital_beds'], icu_units=variables['icu_units'])
     ctx = model.Context(pop_params, hc, create_disease_params(variables), variables['start_date'],
                         random_seed=variables['random_seed'] if seed is None else seed,
-                        device=device, engine_factory=engine_factory)
+                        device=device, engine_factory=engine_factory, comm=comm)
     if interventions is None:
         ivs = get_active_interventions(variables)
     else:

@@ -1,0 +1,65 @@
+"""Worker for tests/test_distributed.py: one rank of a sharded run over torch.distributed (gloo on
+CPU with the oracle-B engine; nccl on GPUs with the HIP engine).  Rank 0 also recomputes the same
+sharded run with all shards in-process and checks that the distributed result is identical."""
+import copy
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    backend = sys.argv[1] if len(sys.argv) > 1 else 'gloo'
+    days = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    total = int(sys.argv[3]) if len(sys.argv) > 3 else 40000
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)))
+        dist.init_process_group('nccl', device_id=torch.device('cuda', int(os.environ.get('LOCAL_RANK', rank))))
+    else:
+        dist.init_process_group('gloo')
+    from reina_model_amd import datasets, sharding, simulation
+    from reina_model_amd import engine as eng
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    import par_backend
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=25, icu_units=3)
+    ages = datasets.scaled_population(total)
+    factory = None if backend == 'nccl' else par_backend.par_engine_factory
+    device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', rank)) if backend == 'nccl' else 'cpu'
+    ctx = simulation.make_context(v, age_counts=ages, seed=21, engine_factory=factory, device=device,
+                                  comm=sharding.TorchComm())
+    hist = ctx.run(days)
+    final = ctx.generate_state()
+    if rank == 0:
+        members = []
+        ref = [simulation.make_context(v, age_counts=ages, seed=21, engine_factory=par_backend.par_engine_factory,
+                                       comm=sharding.InProcessComm(r, world, members)) for r in range(world)]
+        A = eng.MAX_AGES
+        for d in range(days):
+            expect = sharding.reduce_counters(ref)
+            assert np.array_equal(hist[d], expect), 'day %d: distributed history != in-process sharded run' % d
+            sharding.step_shards_together(ref)
+        expect = sharding.reduce_counters(ref)
+        s2 = ref[0].state_from_counters(expect)
+        for k in ('susceptible', 'infected', 'dead', 'all_detected', 'new_infections'):
+            assert np.array_equal(final[k], s2[k]), k
+        assert final['r'] == s2['r'] and final['available_hospital_beds'] == s2['available_hospital_beds']
+        n = int(np.asarray(ages).sum())
+        tot = lambda name: hist[:, eng.C_NAMES.index(name) * A:(eng.C_NAMES.index(name) + 1) * A].sum(axis=1)
+        assert np.all(tot('susceptible') + tot('infected') + tot('recovered') + tot('dead') == n)
+        assert tot('all_infected')[-1] > 1000
+        print('DIST_OK world=%d days=%d all_infected=%d' % (world, days, tot('all_infected')[-1]), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

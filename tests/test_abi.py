@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header_sizes():
     # sizes computed from the header's field lists (all 4/8-byte naturally aligned members)
     A, V, E = eng.MAX_AGES, eng.MAX_VARIANTS, eng.MAX_ENTRIES
-    assert ctypes.sizeof(eng.Config) == 4 * 4 + 8 + 4 * 4 + 4 * (A + 1) + 4  # tail padding to 8
+    assert ctypes.sizeof(eng.Config) == 4 * 4 + 8 + 6 * 4 + 4 * (A + 1) + 4  # tail padding to 8
     assert ctypes.sizeof(eng.Disease) == 4 * (11 * V + V * 24 + V * A + 5 * A + 1 + 3 * 16)
     assert ctypes.sizeof(eng.Buffers) == 8 * len(eng.BUFFER_FIELDS)
     assert ctypes.sizeof(eng.Day) == 8 * 4 + 16 * 16 + 16 * 16 + 8

@@ -1,0 +1,45 @@
+"""N>1 path: world_size-2 `gloo` run on CPU (oracle-B engines behind the product's host code and
+`sharding.TorchComm`) must equal the same sharded run stepped in one process."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, backend, days, total, timeout=600):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'tests', 'dist_worker.py'), backend, str(days), str(total)]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1')
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('world', [2, 3])
+def test_gloo_sharded_run_equals_in_process_sharded_run(world):
+    r = _launch(world, 'gloo', 100, 40000)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'DIST_OK world=%d' % world in r.stdout
+
+
+def test_population_split_is_a_partition():
+    import numpy as np
+    from reina_model_amd import datasets, sharding
+    ages = datasets.get_population_for_area()
+    for world in (2, 3, 8):
+        parts = [sharding.split_population(ages, r, world) for r in range(world)]
+        assert np.array_equal(np.sum(parts, axis=0), ages)
+        assert max(p.sum() for p in parts) - min(p.sum() for p in parts) <= len(ages)
+        assert sum(sharding.split_count(2600, r, world) for r in range(world)) == 2600

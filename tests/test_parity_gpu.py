@@ -154,3 +154,28 @@ def test_conservation_at_scale():
     assert np.all(sc[:, eng.S_DAILY_CONTACTS:eng.S_DAILY_CONTACTS + 6].sum(axis=1) == sc[:, eng.S_EXPOSED_PER_DAY])
     assert tot('all_infected')[-1] > 100000
     assert np.all(sc[:, eng.S_PROBLEM] == 0)
+
+
+def test_sharded_population_two_shards_on_one_gpu():
+    """the population split over G=2 engine instances (both on this GPU, stepped in
+    lock-step with the pressure buffers summed in between) == the same on the CPU oracle."""
+    import par_backend
+    from reina_model_amd import sharding
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=30, icu_units=4)
+    ages = datasets.scaled_population(60000)
+    G = 2
+    gm, cm = [], []
+    gpu = [simulation.make_context(v, age_counts=ages, seed=4, comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
+    cpu = [simulation.make_context(v, age_counts=ages, seed=4, comm=sharding.InProcessComm(r, G, cm),
+                                   engine_factory=par_backend.par_engine_factory) for r in range(G)]
+    for d in range(160):
+        sharding.step_shards_together(gpu)
+        sharding.step_shards_together(cpu)
+        if d % 20 == 19:
+            for a, b in zip(gpu, cpu):
+                assert np.array_equal(a.engine.read_counters(), b.engine.read_counters()), d
+    for a, b in zip(gpu, cpu):
+        _assert_state_equal(a, b)
+    tot = sharding.reduce_counters(gpu)
+    assert tot[eng.C_NAMES.index('all_infected') * eng.MAX_AGES:][:101].sum() > 5000
