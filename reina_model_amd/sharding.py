@@ -46,11 +46,21 @@ class TorchComm:
             return self.torch.from_numpy(buf)  # shares memory: the reduction lands in the array
         return buf
 
+    def _all_reduce(self, buf, op):
+        t = self._as_tensor(buf)
+        if self.dist.get_backend(self.group) == 'nccl' and not t.is_cuda:
+            # RCCL reduces device memory only: stage host-side counter blocks through HBM
+            tmp = t.to(self.torch.device('cuda', self.torch.cuda.current_device()))
+            self.dist.all_reduce(tmp, op=op, group=self.group)
+            t.copy_(tmp.cpu())
+        else:
+            self.dist.all_reduce(t, op=op, group=self.group)
+
     def all_reduce_sum(self, buf):
-        self.dist.all_reduce(self._as_tensor(buf), op=self.dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(buf, self.dist.ReduceOp.SUM)
 
     def all_reduce_max(self, buf):
-        self.dist.all_reduce(self._as_tensor(buf), op=self.dist.ReduceOp.MAX, group=self.group)
+        self._all_reduce(buf, self.dist.ReduceOp.MAX)
 
 
 class InProcessComm:
