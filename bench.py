@@ -104,8 +104,7 @@ def roofline_obj(n_agents, steps, prof, stats):
                 frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
                 bytes_per_launch=bytes_per_launch, avg_launch_ms=round(ms, 6), launches=launches,
                 day_algorithmic_bytes=round((4.0 * n_agents * steps + 4.0 * stats['mean_infected'] * steps
-                                             + 4.0 * stats['contacts'] + 12.0 * stats['new_infections']) / steps, 1),
-                all_kernels_ms_per_day=round(prof['all_ms_total'] / steps, 6))
+                                             + 4.0 * stats['contacts'] + 12.0 * stats['new_infections']) / steps, 1))
 
 
 def cpu_baseline(variables, ages, seed, days):

@@ -58,8 +58,19 @@ class ContactMatrix:
         self.mobility_factor = np.float32(1.0)
         self.mobility_factor_changed = False
         self.mask_probabilities = np.zeros((nr_ages, len(PLACES)), dtype=np.float64)
-        # per-age row lists in original order
+        # per-age row lists in original order, and the reference's entry order per age
+        # (sort_index on (place_type string, contact_age tuple); depends only on the keys)
         self._rows_of_age = [np.nonzero(self._page == a)[0] for a in range(nr_ages)]
+        self._sorted_rows = []
+        for a in range(nr_ages):
+            rows = self._rows_of_age[a]
+            order = np.lexsort((self._cmax[rows], self._cmin[rows], self._rank[rows]))
+            self._sorted_rows.append(rows[order])
+        counts = {len(r) for r in self._rows_of_age}
+        self._uniform = len(counts) == 1 and counts != {0}
+        if self._uniform:
+            self._rows_mat = np.stack(self._rows_of_age)      # [A, E] original order (Kahan order)
+            self._sorted_mat = np.stack(self._sorted_rows)    # [A, E] table order
         self.tables = None
         self.generate_contact_probabilities()
 
@@ -114,36 +125,56 @@ class ContactMatrix:
             contacts[f] *= float(factor)
 
         A = self.nr_ages
-        totals = np.zeros(A, dtype=np.float64)
-        offset = np.zeros(A, dtype=np.int32)
-        count = np.zeros(A, dtype=np.int32)
-        places, cmins, cmaxs, cums, masks = [], [], [], [], []
-        pos = 0
-        for a in range(A):
-            rows = self._rows_of_age[a]
-            c = contacts[rows]
-            # pandas groupby(...).sum(): Kahan summation in row order
-            sumx = 0.0
-            comp = 0.0
-            for v in c.tolist():
-                y = v - comp
+        if self._uniform:
+            # all ages at once: Kahan-compensated sums (pandas groupby-sum) over the row axis
+            c = contacts[self._rows_mat]                      # [A, E]
+            sumx = np.zeros(A, dtype=np.float64)
+            comp = np.zeros(A, dtype=np.float64)
+            for k in range(c.shape[1]):
+                y = c[:, k] - comp
                 t = sumx + y
                 comp = t - sumx - y
                 sumx = t
-            totals[a] = sumx
-            # sort_index on (place_type, contact_age); stable w.r.t. original order
-            order = np.lexsort((self._cmax[rows], self._cmin[rows], self._rank[rows]))
-            r = rows[order]
+            totals = sumx
+            r = self._sorted_mat
             with np.errstate(divide='ignore', invalid='ignore'):
-                cum = np.cumsum(contacts[r] / sumx)
-            offset[a] = pos
-            count[a] = len(r)
-            pos += len(r)
-            places.append(self._place[r])
-            cmins.append(self._cmin[r])
-            cmaxs.append(self._cmax[r])
-            cums.append(cum)
-            masks.append(self.mask_probabilities[a, self._place[r]].astype(np.float32))
+                cum = np.cumsum(contacts[r] / totals[:, None], axis=1)
+            E = r.shape[1]
+            offset = (np.arange(A) * E).astype(np.int32)
+            count = np.full(A, E, dtype=np.int32)
+            rf = r.reshape(-1)
+            places = [self._place[rf]]
+            cmins = [self._cmin[rf]]
+            cmaxs = [self._cmax[rf]]
+            cums = [cum.reshape(-1)]
+            masks = [self.mask_probabilities[np.repeat(np.arange(A), E), self._place[rf]].astype(np.float32)]
+        else:
+            totals = np.zeros(A, dtype=np.float64)
+            offset = np.zeros(A, dtype=np.int32)
+            count = np.zeros(A, dtype=np.int32)
+            places, cmins, cmaxs, cums, masks = [], [], [], [], []
+            pos = 0
+            for a in range(A):
+                rows = self._rows_of_age[a]
+                sumx = 0.0
+                comp = 0.0
+                for v in contacts[rows].tolist():  # pandas groupby(...).sum(): Kahan, row order
+                    y = v - comp
+                    t = sumx + y
+                    comp = t - sumx - y
+                    sumx = t
+                totals[a] = sumx
+                r = self._sorted_rows[a]
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    cum = np.cumsum(contacts[r] / sumx)
+                offset[a] = pos
+                count[a] = len(r)
+                pos += len(r)
+                places.append(self._place[r])
+                cmins.append(self._cmin[r])
+                cmaxs.append(self._cmax[r])
+                cums.append(cum)
+                masks.append(self.mask_probabilities[a, self._place[r]].astype(np.float32))
         self.tables = ContactTables(
             totals, offset, count,
             np.concatenate(places).astype(np.int32), np.concatenate(cmins).astype(np.int32),

@@ -19,6 +19,7 @@
 // geometry.  Integer results are bit-identical to oracle/reina_par.c by construction (same
 // primitives header, FP contraction off).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <climits>
 #include <cstdio>
@@ -1597,11 +1598,6 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
     hipStream_t s = (hipStream_t)stream;
     const reina_day_t dp = *day;
     const uint32_t N = e->cfg.n_agents;
-    size_t ev_day0 = 0, ev_s0 = 0, ev_s1 = 0;
-    if (e->profile) {
-        ev_day0 = take_event(e);
-        hipEventRecord(e->ev_pool[ev_day0], s);
-    }
     hipLaunchKernelGGL(k_prologue, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
     if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
     if (e->testing_ever) {
@@ -1613,21 +1609,20 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
         }
     }
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
-    if (e->profile) {
-        ev_s0 = take_event(e);
-        hipEventRecord(e->ev_pool[ev_s0], s);
-    }
     // scan geometry: tiles of 512 agents; every wave gets >= 4 tiles when the population is small
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
     uint32_t scan_blocks = (scan_tiles / 4u + SCAN_WAVES - 1) / SCAN_WAVES;
     if (scan_blocks < 1) scan_blocks = 1;
     if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
     const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
-    hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SCAN_THREADS), 0, s, e->d_params, e->buf, dp);
     if (e->profile) {
-        ev_s1 = take_event(e);
-        hipEventRecord(e->ev_pool[ev_s1], s);
+        // start/stop timestamps ride on the kernel's own dispatch packet: no extra stream commands
+        const size_t ev_s0 = take_event(e), ev_s1 = take_event(e);
+        hipExtLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SCAN_THREADS), 0, s, e->ev_pool[ev_s0], e->ev_pool[ev_s1], 0,
+                              e->d_params, e->buf, dp);
         e->scan_pairs.emplace_back(ev_s0, ev_s1);
+    } else {
+        hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SCAN_THREADS), 0, s, e->d_params, e->buf, dp);
     }
     hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s, e->d_params, e->buf, dp);
     {
@@ -1636,7 +1631,6 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
         hipLaunchKernelGGL(k_contacts, dim3(con_blocks), dim3(CON_THREADS), con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards), s,
                            e->d_params, e->d_tables, e->buf, dp, scan_waves, scan_tiles, e->uniform_meta);
     }
-    e->ev_day0 = ev_day0;
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
@@ -1650,11 +1644,6 @@ int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) 
     if (e->cfg.n_shards > 1)
         hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256)), dim3(256), 0, s, e->d_params, e->buf, dp);
     hipLaunchKernelGGL(k_install, dim3(grid_for(N / 64 + 1, 256, 512)), dim3(256), 0, s, e->d_params, e->buf, dp);
-    if (e->profile) {
-        size_t ev_day1 = take_event(e);
-        hipEventRecord(e->ev_pool[ev_day1], s);
-        e->day_pairs.emplace_back(e->ev_day0, ev_day1);
-    }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }

@@ -139,6 +139,29 @@ def build_disease_struct(disease_params, nr_ages, imported_infection_ages):
     return d, names
 
 
+_static_pack_cache = {}
+
+
+def _static_pack(tables):
+    """(ranges, range id per entry, meta words): depend only on the entry keys, which never change
+    for a given ContactMatrix; cached by the identity of its key arrays."""
+    key = (tables.place.tobytes(), tables.cmin.tobytes(), tables.cmax.tobytes())
+    hit = _static_pack_cache.get(key)
+    if hit is None:
+        pairs = list(zip(tables.cmin.tolist(), tables.cmax.tolist()))
+        ranges = sorted(set(pairs))
+        if len(ranges) > _eng.MAX_RANGES:
+            raise ValueError('more than %d distinct contact age ranges' % _eng.MAX_RANGES)
+        range_id = {r: k for k, r in enumerate(ranges)}
+        rid = np.asarray([range_id[r] for r in pairs], dtype=np.uint32)
+        m_all = (tables.place.astype(np.uint32) | (tables.cmin.astype(np.uint32) << 8)
+                 | (tables.cmax.astype(np.uint32) << 16) | (rid << 24))
+        hit = (ranges, m_all)
+        _static_pack_cache.clear()
+        _static_pack_cache[key] = hit
+    return hit
+
+
 def pack_contact_tables(tables, nr_ages):
     """ContactTables (contacts.py) -> the fixed-shape arrays of reina_contact_tables_t."""
     E = _eng.MAX_ENTRIES
@@ -147,24 +170,23 @@ def pack_contact_tables(tables, nr_ages):
     count = np.zeros(_eng.MAX_AGES, dtype=np.int32)
     thr = np.full((_eng.MAX_AGES, E), 0xFFFFFFFF, dtype=np.uint32)
     meta = np.zeros((_eng.MAX_AGES, E), dtype=np.uint32)
-    ranges = sorted(set(zip(tables.cmin.tolist(), tables.cmax.tolist())))
-    if len(ranges) > _eng.MAX_RANGES:
-        raise ValueError('more than %d distinct contact age ranges' % _eng.MAX_RANGES)
-    range_id = {r: k for k, r in enumerate(ranges)}
-    rid = np.asarray([range_id[r] for r in zip(tables.cmin.tolist(), tables.cmax.tolist())], dtype=np.uint32)
-    for a in range(nr_ages):
-        o, c = int(tables.offset[a]), int(tables.count[a])
-        if c > E:
-            raise ValueError('more than %d contact entries for age %d' % (E, a))
-        count[a] = c
-        cum = tables.cum_p[o:o + c]
-        with np.errstate(invalid='ignore'):
-            t = np.floor(np.nan_to_num(cum, nan=0.0) * 4294967296.0)
-        thr[a, :c] = np.clip(t, 0, 4294967295.0).astype(np.uint64).astype(np.uint32)
-        meta[a, :c] = (tables.place[o:o + c].astype(np.uint32)
-                       | (tables.cmin[o:o + c].astype(np.uint32) << 8)
-                       | (tables.cmax[o:o + c].astype(np.uint32) << 16)
-                       | (rid[o:o + c] << 24))
+    ranges, m_all = _static_pack(tables)
+    with np.errstate(invalid='ignore'):
+        t_all = np.clip(np.floor(np.nan_to_num(tables.cum_p, nan=0.0) * 4294967296.0), 0, 4294967295.0)
+    t_all = t_all.astype(np.uint64).astype(np.uint32)
+    cnt = tables.count[:nr_ages].astype(np.int64)
+    if cnt.max() > E:
+        raise ValueError('more than %d contact entries for an age' % E)
+    count[:nr_ages] = cnt
+    if np.all(cnt == cnt[0]) and np.array_equal(tables.offset[:nr_ages], np.arange(nr_ages) * cnt[0]):
+        c = int(cnt[0])
+        thr[:nr_ages, :c] = t_all.reshape(nr_ages, c)
+        meta[:nr_ages, :c] = m_all.reshape(nr_ages, c)
+    else:
+        for a in range(nr_ages):
+            o, c = int(tables.offset[a]), int(tables.count[a])
+            thr[a, :c] = t_all[o:o + c]
+            meta[a, :c] = m_all[o:o + c]
     return nrc, count, thr, meta, ranges
 
 
@@ -264,6 +286,7 @@ class Context:
         self._pending_beds = 0
         self._pending_icu = 0
         self._keep = []
+        self._iv_index = None
 
     # ------------------------------------------------------------------ host helpers
     def _upload_tables(self):
@@ -349,10 +372,15 @@ class Context:
     def _build_day(self, history_ptr=None):
         """Host part of iterate(): interventions dated today, init_day bookkeeping -> reina_day_t.
         Returns (Day, tables_changed)."""
-        today = self.get_date_for_today()
-        for iv in self.interventions:
-            if iv.date == today:
-                self.apply_intervention(iv)
+        if self._iv_index is None or self._iv_index[0] != len(self.interventions):
+            by_date = {}
+            for iv in self.interventions:  # list order is kept within a date (main.pyx:2013-2015)
+                by_date.setdefault(iv.date, []).append(iv)
+            self._iv_index = (len(self.interventions), by_date)
+            self._date0 = date.fromisoformat(self.start_date)
+        today = (self._date0 + timedelta(days=self.day)).isoformat()
+        for iv in self._iv_index[1].get(today, ()):
+            self.apply_intervention(iv)
         changed = self.contact_matrix.init_day()
         # Population.infect_people_daily (main.pyx:1671-1685): float32 leftover arithmetic
         weekly = []
