@@ -577,6 +577,9 @@ enum { SL_INFECTED = 0, SL_RECOVERED, SL_DEAD, SL_NHD, SL_NR };
 struct ScanShared {
     int32_t age_start[REINA_MAX_AGES + 1];
     float iot[REINA_MAX_VARIANTS][REINA_IOT_LEN + 3];
+    float nrc[REINA_MAX_AGES];
+    float p_asym[REINA_MAX_VARIANTS];
+    uint32_t age_lut[256];               // age of agent (k * n_agents / 256): start of the age search
     int32_t cnt[SL_NR][REINA_MAX_AGES];
     int32_t total_infectors, total_infections, exposed;
     uint2 q_exp[SCAN_WAVES][SCAN_QCAP];   // (agent, hot word at start of day)
@@ -621,6 +624,15 @@ __device__ void become_ill(const DevParams *P, const reina_buffers_t &B, const r
     B.hot[i] = w;
 }
 
+enum { EVX_COUNT_R = 4, EVX_RECOVERED_HOME = 5, EVX_DIED_HOME = 6 };
+
+__device__ __forceinline__ int scan_age_of(const DevParams *P, const ScanShared &S, uint32_t i) {
+    // coarse LUT (256 equal index buckets) then a short walk along age_start
+    int age = (int)S.age_lut[(uint32_t)(((uint64_t)i * 256u) / P->n_agents)];
+    while ((uint32_t)S.age_start[age + 1] <= i) age++;
+    return age;
+}
+
 // person_expose_others -> get_exposed_people -> get_nr_contacts (main.pyx:247-281,936-955,
 // 1308-1320): only the COUNT is drawn here; k_contacts realises the contacts
 __device__ void expose_count(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
@@ -633,7 +645,7 @@ __device__ void expose_count(const DevParams *P, const reina_buffers_t &B, const
         const int v = RH_VARIANT(w), sev = RH_SEV(w);
         const int dayrel = st == RS_INCUBATION ? -(int)RH_DAYS_LEFT(w) : (int)RH_DOI(w);
         const float inf = S.iot[v][dayrel + 10];
-        const int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
+        const int age = scan_age_of(P, S, i);
         float factor = 1.0f;
         int limit = 100;
         if (st == RS_ILLNESS && sev != RV_ASYMPTOMATIC) {
@@ -641,7 +653,7 @@ __device__ void expose_count(const DevParams *P, const reina_buffers_t &B, const
             limit = 5;
         }
         float z = rp_normal_from_u32(rp_philox(P->k0, P->k1, i, dp.day, RP_P_NRCONTACTS, 0).v[0]);
-        float f = rp_expf(0.5f * z) * P->nrc[age];
+        float f = rp_expf(0.5f * z) * S.nrc[age];
         f *= factor;
         if (f < 1.0f) f = 1.0f;
         nr = (int)f - 1;
@@ -649,7 +661,7 @@ __device__ void expose_count(const DevParams *P, const reina_buffers_t &B, const
         rec = make_uint4(i, (uint32_t)nr | ((uint32_t)v << 8) | ((uint32_t)age << 16), 0u, 0u);
         if (nr > 0) {
             float src_inf = inf;
-            if (sev == RV_ASYMPTOMATIC) src_inf *= d.p_asymptomatic_infection[v];
+            if (sev == RV_ASYMPTOMATIC) src_inf *= S.p_asym[v];
             rec.z = rp_f2u(src_inf);
         }
     }
@@ -667,17 +679,46 @@ __device__ void expose_count(const DevParams *P, const reina_buffers_t &B, const
     if (tot && lane_id() == 0) atomicAdd(&S.exposed, tot);
 }
 
-__device__ void emit_events(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, bool act, uint32_t i, int type) {
-    if (!act) return;
-    uint32_t pos = wave_alloc(&B.control[REINA_L_HOSP]);
-    if (pos >= REINA_MAX_HOSP_EVENTS) {
-        set_problem(B.counters, REINA_PROBLEM_HOSPITAL_OVERFLOW);
-        return;
+// 64 queued "events" at a time: bed / ICU requests and releases become priority-keyed records for
+// k_hospital; the bookkeeping kinds (R statistics, recovered / died at home counters) are batched
+// here so that the streaming lanes never wait on a gather or an age lookup
+__device__ void emit_events(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
+                            bool act, uint32_t i, int type) {
+    const bool hosp = act && type <= EV_RELEASE_ICU;
+    if (__any(hosp)) {
+        if (hosp) {
+            uint32_t pos = wave_alloc(&B.control[REINA_L_HOSP]);
+            if (pos >= REINA_MAX_HOSP_EVENTS) {
+                set_problem(B.counters, REINA_PROBLEM_HOSPITAL_OVERFLOW);
+            } else {
+                uint64_t prio = rp_priority20(P->k0, P->k1, i, dp.day);
+                B.hosp_events[pos] = (prio << 34) | ((uint64_t)i << 2) | (uint64_t)type;
+                if (type == EV_HOSPITALIZE) atomicAdd(&B.control[REINA_L_HOSP_ADMIT], 1);
+                if (type == EV_TO_ICU) atomicAdd(&B.control[REINA_L_ICU_ADMIT], 1);
+            }
+        }
     }
-    uint64_t prio = rp_priority20(P->k0, P->k1, i, dp.day);
-    B.hosp_events[pos] = (prio << 34) | ((uint64_t)i << 2) | (uint64_t)type;
-    if (type == EV_HOSPITALIZE) atomicAdd(&B.control[REINA_L_HOSP_ADMIT], 1);
-    if (type == EV_TO_ICU) atomicAdd(&B.control[REINA_L_ICU_ADMIT], 1);
+    // R bookkeeping: the first scan that sees a removed agent (main.pyx:1969-1972); once per agent
+    const bool cr = act && type == EVX_COUNT_R;
+    const uint64_t mr = __ballot(cr);
+    if (mr) {
+        int ni = cr ? B.n_infected[i] : 0;
+        int tot = wave_sum(ni);
+        if (lane_id() == 0) {
+            atomicAdd(&S.total_infectors, (int)__popcll(mr));
+            if (tot) atomicAdd(&S.total_infections, tot);
+        }
+    }
+    if (act && (type == EVX_RECOVERED_HOME || type == EVX_DIED_HOME)) {
+        const int age = scan_age_of(P, S, i);
+        atomicAdd(&S.cnt[SL_INFECTED][age], -1);
+        if (type == EVX_RECOVERED_HOME) {
+            atomicAdd(&S.cnt[SL_RECOVERED][age], 1);
+        } else {
+            atomicAdd(&S.cnt[SL_DEAD][age], 1);
+            atomicAdd(&S.cnt[SL_NHD][age], 1);
+        }
+    }
 }
 
 // wave-private LDS queues: all accesses come from one wave and LDS executes a wave's operations
@@ -706,7 +747,21 @@ __device__ __forceinline__ bool wq_pop64(volatile uint2 *q, int &qn, uint32_t &x
     return act;
 }
 
+#ifdef REINA_SCAN_STAMPS
+#define STAMP(acc, t0)                                              \
+    {                                                                \
+        unsigned long long t1_ = __builtin_amdgcn_s_memtime();      \
+        (acc) += t1_ - (t0);                                         \
+        (t0) = t1_;                                                  \
+    }
+#else
+#define STAMP(acc, t0)
+#endif
+
 struct ScanQueues {
+#ifdef REINA_SCAN_STAMPS
+    unsigned long long t0, t_load, t_round, t_exp, t_ill, t_ev;
+#endif
     volatile uint2 *exp_, *ill, *ev;
     int n_exp, n_ill, n_ev;
     uint32_t slice_base, slice_n;  // this wave's slice of work_items
@@ -715,18 +770,22 @@ struct ScanQueues {
 __device__ __forceinline__ void scan_drain(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
                                            ScanQueues &Q, int min_fill) {
     uint32_t x, y;
+    STAMP(Q.t_round, Q.t0)
     while (Q.n_exp >= min_fill && Q.n_exp > 0) {
         bool act = wq_pop64(Q.exp_, Q.n_exp, x, y);
         expose_count(P, B, dp, S, act, x, y, Q.slice_base, Q.slice_n);
     }
+    STAMP(Q.t_exp, Q.t0)
     while (Q.n_ill >= min_fill && Q.n_ill > 0) {
         bool act = wq_pop64(Q.ill, Q.n_ill, x, y);
         if (act) become_ill(P, B, dp, x, y);
     }
+    STAMP(Q.t_ill, Q.t0)
     while (Q.n_ev >= min_fill && Q.n_ev > 0) {
         bool act = wq_pop64(Q.ev, Q.n_ev, x, y);
-        emit_events(P, B, dp, act, x, (int)y);
+        emit_events(P, B, dp, S, act, x, (int)y);
     }
+    STAMP(Q.t_ev, Q.t0)
 }
 
 // the cheap in-place part for one hot word; returns the word to store (or `w` itself when nothing
@@ -738,11 +797,10 @@ __device__ __forceinline__ uint32_t scan_word(const DevParams *P, const reina_bu
     bool p_exp = false, p_ill = false, p_ev = false;
     uint32_t ev_type = 0, nw = w;
     if (valid && st >= RS_RECOVERED && !(w & RH_INCLUDED)) {
-        // R bookkeeping: the first scan that sees a removed agent (main.pyx:1969-1972); once per agent
-        atomicAdd(&S.total_infectors, 1);
-        int ni = B.n_infected[i];
-        if (ni) atomicAdd(&S.total_infections, ni);
+        // removed, not yet counted into R: mark it; the n_infected gather is batched (event queue)
         nw = w | RH_INCLUDED;
+        p_ev = true;
+        ev_type = EVX_COUNT_R;
     }
     if (infected) {
         if (st == RS_INCUBATION && (w & RH_FRESH)) {  // infected earlier today: waits (main.pyx:402)
@@ -765,19 +823,14 @@ __device__ __forceinline__ uint32_t scan_word(const DevParams *P, const reina_bu
                     if (dl > 0) dl--;
                     nw = RH_SET_DOI(RH_SET_DAYS_LEFT(w, dl), doi);
                     if (dl == 0) {
+                        p_ev = true;  // per-age counters are updated in batches (event queue)
                         if (sev == RV_FATAL && (w & RH_POD_OUTSIDE)) {
-                            int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
-                            atomicAdd(&S.cnt[SL_INFECTED][age], -1);
-                            atomicAdd(&S.cnt[SL_DEAD][age], 1);
-                            atomicAdd(&S.cnt[SL_NHD][age], 1);
+                            ev_type = EVX_DIED_HOME;
                             nw = RH_SET_STATE(nw, RS_DEAD) & ~RH_HASLIST;
                         } else if (sev >= RV_SEVERE) {
-                            p_ev = true;
                             ev_type = EV_HOSPITALIZE;
                         } else {
-                            int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
-                            atomicAdd(&S.cnt[SL_INFECTED][age], -1);
-                            atomicAdd(&S.cnt[SL_RECOVERED][age], 1);
+                            ev_type = EVX_RECOVERED_HOME;
                             nw = RH_SET_STATE(nw, RS_RECOVERED) & ~RH_HASLIST;
                         }
                     }
@@ -805,10 +858,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
     for (int k = tid; k < REINA_MAX_VARIANTS * (REINA_IOT_LEN + 3); k += SCAN_THREADS)
         (&S.iot[0][0])[k] = (&P->dis.infectiousness_over_time[0][0])[k];
     for (int k = tid; k < SL_NR * REINA_MAX_AGES; k += SCAN_THREADS) (&S.cnt[0][0])[k] = 0;
+    for (int k = tid; k < REINA_MAX_AGES; k += SCAN_THREADS) S.nrc[k] = P->nrc[k];
+    if (tid < REINA_MAX_VARIANTS) S.p_asym[tid] = P->dis.p_asymptomatic_infection[tid];
     if (tid == 0) {
         S.total_infectors = 0;
         S.total_infections = 0;
         S.exposed = 0;
+    }
+    __syncthreads();
+    {   // age LUT: age of the first agent of each of 256 equal index buckets
+        const uint32_t first = (uint32_t)(((uint64_t)tid * P->n_agents + 255u) / 256u);
+        S.age_lut[tid] = (uint32_t)age_of(S.age_start, first < P->n_agents ? first : P->n_agents - 1, 0, (int)P->nr_ages - 1);
     }
     __syncthreads();
     ScanQueues Q;
@@ -816,6 +876,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
     Q.ill = S.q_ill[wave];
     Q.ev = S.q_ev[wave];
     Q.n_exp = Q.n_ill = Q.n_ev = 0;
+#ifdef REINA_SCAN_STAMPS
+    Q.t_load = Q.t_round = Q.t_exp = Q.t_ill = Q.t_ev = 0;
+    Q.t0 = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t N = P->n_agents;
     const uint32_t n4 = N >> 2;
     uint4 *hot4 = reinterpret_cast<uint4 *>(B.hot);
@@ -827,21 +891,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
         Q.slice_base = 512u * (wave_global * tq + (wave_global < tr ? wave_global : tr));
         Q.slice_n = 0;
     }
+    // software pipeline: the next tile's two 1-KiB loads are in flight while this tile is worked on
+    uint4 na_ = make_uint4(0, 0, 0, 0), nb_ = make_uint4(0, 0, 0, 0);
+    {
+        const uint32_t q0 = wave_global * 128u + lane, q1 = q0 + 64u;
+        if (wave_global < tiles) {
+            if (q0 < n4) na_ = hot4[q0];
+            if (q1 < n4) nb_ = hot4[q1];
+        }
+    }
     for (uint32_t t = wave_global; t < tiles; t += waves_total) {
         const uint32_t q0 = t * 128u + lane, q1 = q0 + 64u;
-        const bool v0 = q0 < n4, v1 = q1 < n4;
-        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-        if (v0) a = hot4[q0];
-        if (v1) b = hot4[q1];
-        // which of this lane's 8 words need the state machine today: infected (state 1..4) or
-        // removed but not yet counted into R.  Susceptible / counted words cost these few ops.
-        uint32_t mask = 0;
-#define NEED_BIT(wd, k)                                                                       \
-        {                                                                                     \
-            uint32_t st_ = (wd) & 7u;                                                         \
-            bool need_ = (st_ - 1u) < 4u || (st_ >= (uint32_t)RS_RECOVERED && !((wd) & RH_INCLUDED)); \
-            mask |= (need_ ? 1u : 0u) << (k);                                                 \
+        const uint4 a = na_, b = nb_;
+        {
+            const uint32_t tn = t + waves_total;
+            const uint32_t p0 = tn * 128u + lane, p1 = p0 + 64u;
+            na_ = make_uint4(0, 0, 0, 0);
+            nb_ = make_uint4(0, 0, 0, 0);
+            if (tn + 1 < tiles) {          // interior tile: no bounds checks
+                na_ = hot4[p0];
+                nb_ = hot4[p1];
+            } else if (tn < tiles) {
+                if (p0 < n4) na_ = hot4[p0];
+                if (p1 < n4) nb_ = hot4[p1];
+            }
         }
+        // which of this lane's 8 words need the state machine today: infected (state 1..4) or
+        // removed but not yet counted into R.  With x = state | counted-bit, that is 1 <= x <= 6
+        // (counted removed agents have x = 0x405 / 0x406, susceptible ones 0).
+        uint32_t mask = 0;
+#ifdef REINA_SCAN_STAMPS
+        {   // force the wait for this tile's data here so it is attributed to "load"
+            uint32_t probe = a.x ^ b.w;
+            asm volatile("" ::"v"(probe));
+            STAMP(Q.t_load, Q.t0)
+        }
+#endif
+#define NEED_BIT(wd, k) mask |= ((((wd) & 0x407u) - 1u) < 6u ? 1u : 0u) << (k);
         NEED_BIT(a.x, 0) NEED_BIT(a.y, 1) NEED_BIT(a.z, 2) NEED_BIT(a.w, 3)
         NEED_BIT(b.x, 4) NEED_BIT(b.y, 5) NEED_BIT(b.z, 6) NEED_BIT(b.w, 7)
 #undef NEED_BIT
@@ -875,6 +961,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
         if (in && nw != w) B.hot[i] = nw;
     }
     scan_drain(P, B, dp, S, Q, 1);
+#ifdef REINA_SCAN_STAMPS
+    if (lane == 0) {
+        atomicAdd(&B.counters[SC_IDX(12)], (int)(Q.t_load >> 10));
+        atomicAdd(&B.counters[SC_IDX(13)], (int)(Q.t_round >> 10));
+        atomicAdd(&B.counters[SC_IDX(14)], (int)(Q.t_exp >> 10));
+        atomicAdd(&B.counters[SC_IDX(15)], (int)(Q.t_ill >> 10));
+        atomicAdd(&B.counters[SC_IDX(28)], (int)(Q.t_ev >> 10));
+        atomicAdd(&B.counters[SC_IDX(29)], 1);
+    }
+#endif
     if (lane == 0) B.work_counts[wave_global] = Q.slice_n;
     __syncthreads();
     for (int k = tid; k < SL_NR * REINA_MAX_AGES; k += SCAN_THREADS) {
