@@ -173,8 +173,12 @@ typedef struct {
                                  a day-tagged hash sample of this shard's OUTGOING cross-shard attempts,
                                  from which an incoming infection takes a local stand-in infector
                                  ("mirror attribution", reina_model_amd/sharding.py) */
-    uint32_t *work_counts;    /* [REINA_MAX_SCAN_WAVES] work items written by each scanning wave into
-                                 its private slice of work_items (no global append counter) */
+    uint32_t *work_counts;    /* [4 * REINA_MAX_SCAN_WAVES] entries written by each scanning wave into its
+                                 private slice of the four scan lists (no global append counter):
+                                 exposure candidates, symptom onsets, hospital events, bookkeeping */
+    uint32_t *scan_lists;     /* [4 * max_work_items] two lists of (agent, kind) pairs written by the
+                                 scan: hospital events, then bookkeeping (R statistics, home
+                                 recoveries / deaths). The other two lists live in work_items. */
     uint32_t *sus_bits;       /* [ceil(N/32)] bit i set <=> agent i is SUSCEPTIBLE (never infected):
                                  the only thing a sampled contact needs to know about its target
                                  (person_expose, main.pyx:239), 1 bit instead of a 64-byte struct */

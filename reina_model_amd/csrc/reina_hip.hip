@@ -48,6 +48,7 @@ struct DevParams {
     int32_t tcount[REINA_MAX_AGES];
     float mask_p[REINA_MAX_AGES][8];
     // sharding
+    uint32_t iot_mask[REINA_MAX_VARIANTS];   // bit (day+10) set when infectiousness_over_time[v][day+10] != 0
     uint32_t n_shards, shard_rank, mirror_slots;
     float psus_max[REINA_MAX_VARIANTS];
     uint32_t n_ranges;
@@ -562,35 +563,28 @@ __global__ void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t 
 // ---------------------------------------------------------------------------------------------
 // k_scan: Context._process_person + person_advance for every agent (main.pyx:1968-1992,395-438)
 //
-// Streaming lanes: each lane loads 16 B (4 hot words) and runs the cheap integer part of the state
-// machine in place (countdown, recover / die at home) and stores changed words back next to where
-// it loaded them.  Everything expensive is compacted with wave ballots into wave-private LDS
-// queues and executed 64 at a time with every lane busy:
-//   expose queue : infectious, undetected agents -> Philox + lognormal contact COUNT -> work item
-//   onset queue  : incubation ran out -> gamma draw of the illness course, testing decision
-//   event queue  : bed / ICU requests and releases -> priority-keyed event for k_hospital
+// A pure streaming kernel: each lane loads 16 B (4 hot words) per 1-KiB wave load, two loads in
+// flight per wave; a per-lane need-mask picks the words that are infected or removed-but-uncounted
+// (everything else costs three integer ops).  The integer part of the state machine (countdown,
+// recover / die at home, R marking) runs in place and changed words are stored back where they
+// were loaded.  Everything that needs random numbers, gathers or counters is only RECORDED here,
+// as (agent, word|kind) pairs appended with wave ballots to four per-wave slices -- no atomics,
+// no LDS -- and executed densely by the kernels that follow:
+//   exposure candidates  -> k_contacts (contact COUNT draw, then the contacts themselves)
+//   symptom onsets       -> k_install  (gamma draw of the illness course, testing decision)
+//   hospital events      -> k_hospital (bed / ICU requests and releases in priority order)
+//   bookkeeping          -> k_install  (R statistics, recovered / died-at-home counters)
 #define SCAN_THREADS 256
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define SCAN_QCAP 128
 enum { SL_INFECTED = 0, SL_RECOVERED, SL_DEAD, SL_NHD, SL_NR };
+enum { LIST_EXP = 0, LIST_ILL = 1, LIST_EV = 2, LIST_BOOK = 3 };
+enum { EVX_COUNT_R = 4, EVX_RECOVERED_HOME = 5, EVX_DIED_HOME = 6 };
 
-struct ScanShared {
-    int32_t age_start[REINA_MAX_AGES + 1];
-    float iot[REINA_MAX_VARIANTS][REINA_IOT_LEN + 3];
-    float nrc[REINA_MAX_AGES];
-    float p_asym[REINA_MAX_VARIANTS];
-    uint32_t age_lut[256];               // age of agent (k * n_agents / 256): start of the age search
-    int32_t cnt[SL_NR][REINA_MAX_AGES];
-    int32_t total_infectors, total_infections, exposed;
-    uint2 q_exp[SCAN_WAVES][SCAN_QCAP];   // (agent, hot word at start of day)
-    uint2 q_ill[SCAN_WAVES][SCAN_QCAP];   // (agent, hot word after the countdown)
-    uint2 q_ev[SCAN_WAVES][SCAN_QCAP];    // (agent, event type)
-};
-
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+// entries of scan wave `sw` start here in every list (a wave's slice is as large as the number
+// of agents it scans: tiles sw, sw + W, ... of 512 agents)
+__host__ __device__ __forceinline__ uint32_t scan_slice_base(uint32_t sw, uint32_t scan_waves, uint32_t scan_tiles) {
+    const uint32_t tq = scan_tiles / scan_waves, tr = scan_tiles % scan_waves;
+    return 512u * (sw * tq + (sw < tr ? sw : tr));
 }
 
 // person_become_ill (main.pyx:284-291, 989-1014) + seek_testing (:595-615); `w` already carries
@@ -624,213 +618,65 @@ __device__ void become_ill(const DevParams *P, const reina_buffers_t &B, const r
     B.hot[i] = w;
 }
 
-enum { EVX_COUNT_R = 4, EVX_RECOVERED_HOME = 5, EVX_DIED_HOME = 6 };
-
-__device__ __forceinline__ int scan_age_of(const DevParams *P, const ScanShared &S, uint32_t i) {
-    // coarse LUT (256 equal index buckets) then a short walk along age_start
-    int age = (int)S.age_lut[(uint32_t)(((uint64_t)i * 256u) / P->n_agents)];
-    while ((uint32_t)S.age_start[age + 1] <= i) age++;
-    return age;
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
 }
 
-// person_expose_others -> get_exposed_people -> get_nr_contacts (main.pyx:247-281,936-955,
-// 1308-1320): only the COUNT is drawn here; k_contacts realises the contacts
-__device__ void expose_count(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
-                             bool act, uint32_t i, uint32_t w, uint32_t slice_base, uint32_t &slice_n) {
-    int nr = 0;
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    if (act) {
-        const reina_disease_t &d = P->dis;
-        const uint32_t st = RH_STATE(w);
-        const int v = RH_VARIANT(w), sev = RH_SEV(w);
-        const int dayrel = st == RS_INCUBATION ? -(int)RH_DAYS_LEFT(w) : (int)RH_DOI(w);
-        const float inf = S.iot[v][dayrel + 10];
-        const int age = scan_age_of(P, S, i);
-        float factor = 1.0f;
-        int limit = 100;
-        if (st == RS_ILLNESS && sev != RV_ASYMPTOMATIC) {
-            factor = 0.5f;
-            limit = 5;
-        }
-        float z = rp_normal_from_u32(rp_philox(P->k0, P->k1, i, dp.day, RP_P_NRCONTACTS, 0).v[0]);
-        float f = rp_expf(0.5f * z) * S.nrc[age];
-        f *= factor;
-        if (f < 1.0f) f = 1.0f;
-        nr = (int)f - 1;
-        if (nr > limit) nr = limit;
-        rec = make_uint4(i, (uint32_t)nr | ((uint32_t)v << 8) | ((uint32_t)age << 16), 0u, 0u);
-        if (nr > 0) {
-            float src_inf = inf;
-            if (sev == RV_ASYMPTOMATIC) src_inf *= S.p_asym[v];
-            rec.z = rp_f2u(src_inf);
-        }
-    }
-    // work items go to this wave's private slice of the list: a ballot gives the slots, no atomic
-    const uint64_t m = __ballot(nr > 0);
-    if (nr > 0) {
-        uint32_t pos = slice_base + slice_n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        if (pos >= P->max_work_items)
-            set_problem(B.counters, REINA_PROBLEM_WORK_OVERFLOW);
-        else
-            reinterpret_cast<uint4 *>(B.work_items)[pos] = rec;
-    }
-    slice_n += (uint32_t)__popcll(m);
-    int tot = wave_sum(nr);
-    if (tot && lane_id() == 0) atomicAdd(&S.exposed, tot);
-}
-
-// 64 queued "events" at a time: bed / ICU requests and releases become priority-keyed records for
-// k_hospital; the bookkeeping kinds (R statistics, recovered / died at home counters) are batched
-// here so that the streaming lanes never wait on a gather or an age lookup
-__device__ void emit_events(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
-                            bool act, uint32_t i, int type) {
-    const bool hosp = act && type <= EV_RELEASE_ICU;
-    if (__any(hosp)) {
-        if (hosp) {
-            uint32_t pos = wave_alloc(&B.control[REINA_L_HOSP]);
-            if (pos >= REINA_MAX_HOSP_EVENTS) {
-                set_problem(B.counters, REINA_PROBLEM_HOSPITAL_OVERFLOW);
-            } else {
-                uint64_t prio = rp_priority20(P->k0, P->k1, i, dp.day);
-                B.hosp_events[pos] = (prio << 34) | ((uint64_t)i << 2) | (uint64_t)type;
-                if (type == EV_HOSPITALIZE) atomicAdd(&B.control[REINA_L_HOSP_ADMIT], 1);
-                if (type == EV_TO_ICU) atomicAdd(&B.control[REINA_L_ICU_ADMIT], 1);
-            }
-        }
-    }
-    // R bookkeeping: the first scan that sees a removed agent (main.pyx:1969-1972); once per agent
-    const bool cr = act && type == EVX_COUNT_R;
-    const uint64_t mr = __ballot(cr);
-    if (mr) {
-        int ni = cr ? B.n_infected[i] : 0;
-        int tot = wave_sum(ni);
-        if (lane_id() == 0) {
-            atomicAdd(&S.total_infectors, (int)__popcll(mr));
-            if (tot) atomicAdd(&S.total_infections, tot);
-        }
-    }
-    if (act && (type == EVX_RECOVERED_HOME || type == EVX_DIED_HOME)) {
-        const int age = scan_age_of(P, S, i);
-        atomicAdd(&S.cnt[SL_INFECTED][age], -1);
-        if (type == EVX_RECOVERED_HOME) {
-            atomicAdd(&S.cnt[SL_RECOVERED][age], 1);
-        } else {
-            atomicAdd(&S.cnt[SL_DEAD][age], 1);
-            atomicAdd(&S.cnt[SL_NHD][age], 1);
-        }
-    }
-}
-
-// wave-private LDS queues: all accesses come from one wave and LDS executes a wave's operations
-// in order, so only the compiler has to be kept from reordering (volatile)
-__device__ __forceinline__ void wq_push(volatile uint2 *q, int &qn, bool pred, uint32_t x, uint32_t y) {
-    uint64_t m = __ballot(pred);
-    if (pred) {
-        int pos = qn + (int)__popcll(m & ((1ull << lane_id()) - 1ull));
-        q[pos].x = x;
-        q[pos].y = y;
-    }
-    qn += (int)__popcll(m);
-}
-// pops up to 64 entries (the newest); returns whether this lane holds one
-__device__ __forceinline__ bool wq_pop64(volatile uint2 *q, int &qn, uint32_t &x, uint32_t &y) {
-    int take = qn < 64 ? qn : 64;
-    int base = qn - take;
-    bool act = lane_id() < take;
-    x = 0;
-    y = 0;
-    if (act) {
-        x = q[base + lane_id()].x;
-        y = q[base + lane_id()].y;
-    }
-    qn = base;
-    return act;
-}
-
-#ifdef REINA_SCAN_STAMPS
-#define STAMP(acc, t0)                                              \
-    {                                                                \
-        unsigned long long t1_ = __builtin_amdgcn_s_memtime();      \
-        (acc) += t1_ - (t0);                                         \
-        (t0) = t1_;                                                  \
-    }
-#else
-#define STAMP(acc, t0)
-#endif
-
-struct ScanQueues {
-#ifdef REINA_SCAN_STAMPS
-    unsigned long long t0, t_load, t_round, t_exp, t_ill, t_ev;
-#endif
-    volatile uint2 *exp_, *ill, *ev;
-    int n_exp, n_ill, n_ev;
-    uint32_t slice_base, slice_n;  // this wave's slice of work_items
+struct ScanLists {
+    uint2 *l[4];
+    uint32_t n[4];
 };
 
-__device__ __forceinline__ void scan_drain(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, ScanShared &S,
-                                           ScanQueues &Q, int min_fill) {
-    uint32_t x, y;
-    STAMP(Q.t_round, Q.t0)
-    while (Q.n_exp >= min_fill && Q.n_exp > 0) {
-        bool act = wq_pop64(Q.exp_, Q.n_exp, x, y);
-        expose_count(P, B, dp, S, act, x, y, Q.slice_base, Q.slice_n);
-    }
-    STAMP(Q.t_exp, Q.t0)
-    while (Q.n_ill >= min_fill && Q.n_ill > 0) {
-        bool act = wq_pop64(Q.ill, Q.n_ill, x, y);
-        if (act) become_ill(P, B, dp, x, y);
-    }
-    STAMP(Q.t_ill, Q.t0)
-    while (Q.n_ev >= min_fill && Q.n_ev > 0) {
-        bool act = wq_pop64(Q.ev, Q.n_ev, x, y);
-        emit_events(P, B, dp, S, act, x, (int)y);
-    }
-    STAMP(Q.t_ev, Q.t0)
+__device__ __forceinline__ void list_push(ScanLists &L, int which, bool pred, uint32_t x, uint32_t y) {
+    const uint64_t m = __ballot(pred);
+    if (pred) L.l[which][L.n[which] + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = make_uint2(x, y);
+    L.n[which] += (uint32_t)__popcll(m);
 }
 
-// the cheap in-place part for one hot word; returns the word to store (or `w` itself when nothing
-// changes or the final word is written later by the onset queue)
-__device__ __forceinline__ uint32_t scan_word(const DevParams *P, const reina_buffers_t &B, ScanShared &S, ScanQueues &Q,
-                                               bool valid, uint32_t i, uint32_t w) {
+// the in-place part for one hot word; returns the word to store (`w` itself when nothing changes
+// or when the final word is written later by become_ill)
+__device__ __forceinline__ uint32_t scan_word(const DevParams *P, ScanLists &L, bool valid, uint32_t i, uint32_t w) {
     const uint32_t st = RH_STATE(w);
-    bool infected = valid && st >= RS_INCUBATION && st <= RS_IN_ICU;
-    bool p_exp = false, p_ill = false, p_ev = false;
-    uint32_t ev_type = 0, nw = w;
-    if (valid && st >= RS_RECOVERED && !(w & RH_INCLUDED)) {
-        // removed, not yet counted into R: mark it; the n_infected gather is batched (event queue)
-        nw = w | RH_INCLUDED;
-        p_ev = true;
-        ev_type = EVX_COUNT_R;
-    }
-    if (infected) {
-        if (st == RS_INCUBATION && (w & RH_FRESH)) {  // infected earlier today: waits (main.pyx:402)
-            nw = w & ~RH_FRESH;
+    bool p_exp = false, p_ill = false, p_ev = false, p_bk = false;
+    uint32_t kind = 0, nw = w;
+    if (valid) {
+        if (st >= RS_RECOVERED) {
+            // removed, not yet counted into R (main.pyx:1969-1972): mark; n_infected is gathered later
+            nw = w | RH_INCLUDED;
+            p_bk = true;
+            kind = EVX_COUNT_R;
+        } else if (st == RS_INCUBATION && (w & RH_FRESH)) {
+            nw = w & ~RH_FRESH;  // infected earlier today: waits (main.pyx:402)
         } else {
             const int v = RH_VARIANT(w), sev = RH_SEV(w);
             uint32_t dl = RH_DAYS_LEFT(w);
             if (st <= RS_ILLNESS) {
                 if (!(w & RH_DETECTED)) {
-                    int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w);
-                    p_exp = dayrel >= -10 && dayrel <= 10 && S.iot[v][dayrel + 10] != 0.0f;
+                    const int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w);
+                    p_exp = dayrel >= -10 && dayrel <= 10 && ((P->iot_mask[v] >> (dayrel + 10)) & 1u);
                 }
                 if (st == RS_INCUBATION) {
                     if (dl > 0) dl--;
                     nw = RH_SET_DAYS_LEFT(w, dl);
-                    if (dl == 0) p_ill = true;  // become_ill stores the final word
+                    p_ill = dl == 0;  // become_ill stores the final word
                 } else {
                     uint32_t doi = RH_DOI(w);
                     if (doi < 255) doi++;
                     if (dl > 0) dl--;
                     nw = RH_SET_DOI(RH_SET_DAYS_LEFT(w, dl), doi);
                     if (dl == 0) {
-                        p_ev = true;  // per-age counters are updated in batches (event queue)
                         if (sev == RV_FATAL && (w & RH_POD_OUTSIDE)) {
-                            ev_type = EVX_DIED_HOME;
+                            p_bk = true;
+                            kind = EVX_DIED_HOME;
                             nw = RH_SET_STATE(nw, RS_DEAD) & ~RH_HASLIST;
                         } else if (sev >= RV_SEVERE) {
-                            ev_type = EV_HOSPITALIZE;
+                            p_ev = true;
+                            kind = EV_HOSPITALIZE;
                         } else {
-                            ev_type = EVX_RECOVERED_HOME;
+                            p_bk = true;
+                            kind = EVX_RECOVERED_HOME;
                             nw = RH_SET_STATE(nw, RS_RECOVERED) & ~RH_HASLIST;
                         }
                     }
@@ -840,56 +686,34 @@ __device__ __forceinline__ uint32_t scan_word(const DevParams *P, const reina_bu
                 nw = RH_SET_DAYS_LEFT(w, dl);
                 if (dl == 0) {
                     p_ev = true;
-                    ev_type = st == RS_HOSPITALIZED ? (sev >= RV_CRITICAL ? EV_TO_ICU : EV_RELEASE_WARD) : EV_RELEASE_ICU;
+                    kind = st == RS_HOSPITALIZED ? (sev >= RV_CRITICAL ? EV_TO_ICU : EV_RELEASE_WARD) : EV_RELEASE_ICU;
                 }
             }
         }
     }
-    if (__any(p_exp)) wq_push(Q.exp_, Q.n_exp, p_exp, i, w);
-    if (__any(p_ill)) wq_push(Q.ill, Q.n_ill, p_ill, i, nw);
-    if (__any(p_ev)) wq_push(Q.ev, Q.n_ev, p_ev, i, ev_type);
+    if (__any(p_exp)) list_push(L, LIST_EXP, p_exp, i, w);
+    if (__any(p_ill)) list_push(L, LIST_ILL, p_ill, i, nw);
+    if (__any(p_ev)) list_push(L, LIST_EV, p_ev, i, kind);
+    if (__any(p_bk)) list_push(L, LIST_BOOK, p_bk, i, kind);
     return p_ill ? w : nw;
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
-    __shared__ ScanShared S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k <= REINA_MAX_AGES; k += SCAN_THREADS) S.age_start[k] = P->age_start[k];
-    for (int k = tid; k < REINA_MAX_VARIANTS * (REINA_IOT_LEN + 3); k += SCAN_THREADS)
-        (&S.iot[0][0])[k] = (&P->dis.infectiousness_over_time[0][0])[k];
-    for (int k = tid; k < SL_NR * REINA_MAX_AGES; k += SCAN_THREADS) (&S.cnt[0][0])[k] = 0;
-    for (int k = tid; k < REINA_MAX_AGES; k += SCAN_THREADS) S.nrc[k] = P->nrc[k];
-    if (tid < REINA_MAX_VARIANTS) S.p_asym[tid] = P->dis.p_asymptomatic_infection[tid];
-    if (tid == 0) {
-        S.total_infectors = 0;
-        S.total_infections = 0;
-        S.exposed = 0;
-    }
-    __syncthreads();
-    {   // age LUT: age of the first agent of each of 256 equal index buckets
-        const uint32_t first = (uint32_t)(((uint64_t)tid * P->n_agents + 255u) / 256u);
-        S.age_lut[tid] = (uint32_t)age_of(S.age_start, first < P->n_agents ? first : P->n_agents - 1, 0, (int)P->nr_ages - 1);
-    }
-    __syncthreads();
-    ScanQueues Q;
-    Q.exp_ = S.q_exp[wave];
-    Q.ill = S.q_ill[wave];
-    Q.ev = S.q_ev[wave];
-    Q.n_exp = Q.n_ill = Q.n_ev = 0;
-#ifdef REINA_SCAN_STAMPS
-    Q.t_load = Q.t_round = Q.t_exp = Q.t_ill = Q.t_ev = 0;
-    Q.t0 = __builtin_amdgcn_s_memtime();
-#endif
     const uint32_t N = P->n_agents;
     const uint32_t n4 = N >> 2;
-    uint4 *hot4 = reinterpret_cast<uint4 *>(B.hot);
+    const uint4 *hot4 = reinterpret_cast<const uint4 *>(B.hot);
     // each wave walks tiles of 128 uint4 (two 1-KiB loads in flight per wave)
     const uint32_t tiles = (n4 + 127u) / 128u;
     const uint32_t wave_global = blockIdx.x * SCAN_WAVES + wave, waves_total = gridDim.x * SCAN_WAVES;
-    {   // wave w owns tiles w, w+W, ...; its work items land in a slice as large as the agents it scans
-        const uint32_t tq = tiles / waves_total, tr = tiles % waves_total;
-        Q.slice_base = 512u * (wave_global * tq + (wave_global < tr ? wave_global : tr));
-        Q.slice_n = 0;
+    ScanLists L;
+    {
+        const uint32_t cap = P->max_work_items, base = scan_slice_base(wave_global, waves_total, tiles);
+        L.l[LIST_EXP] = reinterpret_cast<uint2 *>(B.work_items) + base;
+        L.l[LIST_ILL] = reinterpret_cast<uint2 *>(B.work_items) + cap + base;
+        L.l[LIST_EV] = reinterpret_cast<uint2 *>(B.scan_lists) + base;
+        L.l[LIST_BOOK] = reinterpret_cast<uint2 *>(B.scan_lists) + cap + base;
+        L.n[0] = L.n[1] = L.n[2] = L.n[3] = 0;
     }
     // software pipeline: the next tile's two 1-KiB loads are in flight while this tile is worked on
     uint4 na_ = make_uint4(0, 0, 0, 0), nb_ = make_uint4(0, 0, 0, 0);
@@ -920,13 +744,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
         // removed but not yet counted into R.  With x = state | counted-bit, that is 1 <= x <= 6
         // (counted removed agents have x = 0x405 / 0x406, susceptible ones 0).
         uint32_t mask = 0;
-#ifdef REINA_SCAN_STAMPS
-        {   // force the wait for this tile's data here so it is attributed to "load"
-            uint32_t probe = a.x ^ b.w;
-            asm volatile("" ::"v"(probe));
-            STAMP(Q.t_load, Q.t0)
-        }
-#endif
 #define NEED_BIT(wd, k) mask |= ((((wd) & 0x407u) - 1u) < 6u ? 1u : 0u) << (k);
         NEED_BIT(a.x, 0) NEED_BIT(a.y, 1) NEED_BIT(a.z, 2) NEED_BIT(a.w, 3)
         NEED_BIT(b.x, 4) NEED_BIT(b.y, 5) NEED_BIT(b.z, 6) NEED_BIT(b.w, 7)
@@ -946,8 +763,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
             w = k == 6 ? b.z : w;
             w = k == 7 ? b.w : w;
             const uint32_t i = k < 4 ? 4u * q0 + (uint32_t)k : 4u * q1 + (uint32_t)(k - 4);
-            const uint32_t nw = scan_word(P, B, S, Q, valid, i, w);
-            scan_drain(P, B, dp, S, Q, 64);
+            const uint32_t nw = scan_word(P, L, valid, i, w);
             // a deferred (onset) word keeps its old value here and is written by become_ill
             if (valid && nw != w) B.hot[i] = nw;
         }
@@ -957,34 +773,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina
         uint32_t w = 0;
         bool in = lane < (int)(N & 3u);
         if (in) w = B.hot[i];
-        uint32_t nw = scan_word(P, B, S, Q, in, i, w);
-        if (in && nw != w) B.hot[i] = nw;
+        const bool need = in && (((w & 0x407u) - 1u) < 6u);
+        uint32_t nw = scan_word(P, L, need, i, w);
+        if (need && nw != w) B.hot[i] = nw;
     }
-    scan_drain(P, B, dp, S, Q, 1);
-#ifdef REINA_SCAN_STAMPS
-    if (lane == 0) {
-        atomicAdd(&B.counters[SC_IDX(12)], (int)(Q.t_load >> 10));
-        atomicAdd(&B.counters[SC_IDX(13)], (int)(Q.t_round >> 10));
-        atomicAdd(&B.counters[SC_IDX(14)], (int)(Q.t_exp >> 10));
-        atomicAdd(&B.counters[SC_IDX(15)], (int)(Q.t_ill >> 10));
-        atomicAdd(&B.counters[SC_IDX(28)], (int)(Q.t_ev >> 10));
-        atomicAdd(&B.counters[SC_IDX(29)], 1);
-    }
-#endif
-    if (lane == 0) B.work_counts[wave_global] = Q.slice_n;
-    __syncthreads();
-    for (int k = tid; k < SL_NR * REINA_MAX_AGES; k += SCAN_THREADS) {
-        int32_t v = (&S.cnt[0][0])[k];
-        if (v) {
-            int c = k / REINA_MAX_AGES, age = k % REINA_MAX_AGES;
-            const int map[SL_NR] = {REINA_C_INFECTED, REINA_C_RECOVERED, REINA_C_DEAD, REINA_C_NON_HOSPITAL_DEATHS};
-            atomicAdd(&B.counters[CNT_IDX(map[c], age)], v);
-        }
-    }
-    if (tid == 0) {
-        if (S.total_infectors) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTORS)], S.total_infectors);
-        if (S.total_infections) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTIONS)], S.total_infections);
-        if (S.exposed) atomicAdd(&B.counters[SC_IDX(REINA_S_EXPOSED_PER_DAY)], S.exposed);
+    if (lane < 4) {
+        const uint32_t c = lane == 0 ? L.n[0] : lane == 1 ? L.n[1] : lane == 2 ? L.n[2] : L.n[3];
+        B.work_counts[lane * REINA_MAX_SCAN_WAVES + wave_global] = c;
     }
 }
 
@@ -1045,7 +840,8 @@ __device__ __forceinline__ SatFn icu_fn(int type) {
 enum { HL_INFECTED = 0, HL_DETECTED, HL_ALL_DETECTED, HL_HOSPITALIZED, HL_IN_WARD, HL_IN_ICU, HL_CUM_ICU,
        HL_DEAD, HL_NHD, HL_RECOVERED, HL_NR };
 
-__global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, reina_buffers_t B, reina_day_t dp,
+                                                           uint32_t scan_waves, uint32_t scan_tiles) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *ev = reinterpret_cast<uint64_t *>(smem);               // [M2]
     __shared__ int s_b, s_c;
@@ -1053,18 +849,64 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
     __shared__ int32_t s_cnt[HL_NR][REINA_MAX_AGES];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     const int tid = threadIdx.x;
-    int M = B.control[REINA_L_HOSP];
-    if (M > REINA_MAX_HOSP_EVENTS) M = REINA_MAX_HOSP_EVENTS;
+    __shared__ int s_pre[HOSP_THREADS + 1], s_admit[2];
+    // collect the scan's hospital events: exclusive prefix over the per-wave counts
+    const uint32_t per_w = (scan_waves + HOSP_THREADS - 1) / HOSP_THREADS;
+    int mine = 0;
+    for (uint32_t k = 0; k < per_w; k++) {
+        const uint32_t sw = tid * per_w + k;
+        if (sw < scan_waves) mine += (int)B.work_counts[LIST_EV * REINA_MAX_SCAN_WAVES + sw];
+    }
+    s_pre[tid + 1] = mine;
+    if (tid == 0) {
+        s_pre[0] = 0;
+        s_admit[0] = 0;
+        s_admit[1] = 0;
+    }
+    __syncthreads();
+    for (int off = 1; off < HOSP_THREADS; off <<= 1) {
+        int vv = s_pre[tid + 1];
+        if (tid + 1 > off) vv += s_pre[tid + 1 - off];
+        __syncthreads();
+        s_pre[tid + 1] = vv;
+        __syncthreads();
+    }
+    int M = s_pre[HOSP_THREADS];
+    if (M > REINA_MAX_HOSP_EVENTS) {
+        if (tid == 0) set_problem(B.counters, REINA_PROBLEM_HOSPITAL_OVERFLOW);
+        M = REINA_MAX_HOSP_EVENTS;
+    }
     if (M == 0) return;
     int M2 = 1;
     while (M2 < M) M2 <<= 1;
     // an admission that finds no free bed / ICU unit is marked in bit 63 of its event word
     const int b0 = B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)], c0 = B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)];
-    const bool ordered = !(b0 >= B.control[REINA_L_HOSP_ADMIT] && c0 >= B.control[REINA_L_ICU_ADMIT]);
-    for (int k = tid; k < M2; k += HOSP_THREADS) ev[k] = k < M ? B.hosp_events[k] : ~0ull;
+    for (int k = tid; k < M2; k += HOSP_THREADS) ev[k] = ~0ull;
     for (int k = tid; k < HL_NR * REINA_MAX_AGES; k += HOSP_THREADS) (&s_cnt[0][0])[k] = 0;
     if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
     __syncthreads();
+    {   // event word = [priority:20][agent:32][type:2]; the priority is a Philox hash of (agent, day)
+        const uint2 *l_ev = reinterpret_cast<const uint2 *>(B.scan_lists);
+        int pos = s_pre[tid], nh = 0, nt = 0;
+        for (uint32_t k = 0; k < per_w; k++) {
+            const uint32_t sw = tid * per_w + k;
+            if (sw >= scan_waves) break;
+            const uint32_t n = B.work_counts[LIST_EV * REINA_MAX_SCAN_WAVES + sw];
+            const uint32_t base = scan_slice_base(sw, scan_waves, scan_tiles);
+            for (uint32_t j = 0; j < n; j++, pos++) {
+                if (pos >= M) break;
+                const uint2 r = l_ev[base + j];
+                const uint64_t prio = rp_priority20(P->k0, P->k1, r.x, dp.day);
+                ev[pos] = (prio << 34) | ((uint64_t)r.x << 2) | (uint64_t)r.y;
+                nh += r.y == EV_HOSPITALIZE;
+                nt += r.y == EV_TO_ICU;
+            }
+        }
+        if (nh) atomicAdd(&s_admit[0], nh);
+        if (nt) atomicAdd(&s_admit[1], nt);
+    }
+    __syncthreads();
+    const bool ordered = !(b0 >= s_admit[0] && c0 >= s_admit[1]);
     if (ordered) {
         for (int size = 2; size <= M2; size <<= 1) {
             for (int strd = size >> 1; strd > 0; strd >>= 1) {
@@ -1249,6 +1091,8 @@ struct ConShared {
     uint4 item[CON_WAVES][64];          // the wave's current 64 work items
     int32_t daily[REINA_NR_PLACES];
     int32_t n_contacts;
+    float iot[REINA_MAX_VARIANTS][REINA_IOT_LEN + 3];
+    float nrc[REINA_MAX_AGES];
     // dynamic tail: uint32_t thr[nr_ages][REINA_MAX_ENTRIES]; then, when sharded,
     // int32_t pressure[REINA_PRESSURE_WORDS] (this workgroup's outgoing cross-shard pressure)
 };
@@ -1276,26 +1120,55 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
         for (int k = tid; k < REINA_MAX_AGES; k += CON_THREADS) S.tcount[k] = P->tcount[k];
         if (tid < REINA_NR_PLACES) S.daily[tid] = 0;
         if (tid == 0) S.n_contacts = 0;
+        for (int k = tid; k < REINA_MAX_VARIANTS * (REINA_IOT_LEN + 3); k += CON_THREADS)
+            (&S.iot[0][0])[k] = (&P->dis.infectiousness_over_time[0][0])[k];
+        for (int k = tid; k < REINA_MAX_AGES; k += CON_THREADS) S.nrc[k] = P->nrc[k];
         if (P->n_shards > 1)
             for (int k = tid; k < REINA_PRESSURE_WORDS; k += CON_THREADS) S_pressure[k] = 0;
     }
     __syncthreads();
     const reina_disease_t &d = P->dis;
     const uint32_t n_shards = P->n_shards, shard_rank = P->shard_rank;
-    const uint4 *items = reinterpret_cast<const uint4 *>(B.work_items);
+    const uint2 *items = reinterpret_cast<const uint2 *>(B.work_items);
     const uint32_t total_waves = gridDim.x * CON_WAVES;
-    const uint32_t tq = scan_tiles / scan_waves, tr = scan_tiles % scan_waves;
     // candidate slots are reserved CAND_CHUNK at a time (one atomic per chunk, not per hit)
     uint32_t cbase = 0, cused = CAND_CHUNK;
     uint32_t wave_contacts = 0;
     for (uint32_t sw = blockIdx.x * CON_WAVES + wave; sw < scan_waves; sw += total_waves) {
-        const uint32_t slice_base = 512u * (sw * tq + (sw < tr ? sw : tr));
-        const uint32_t W = B.work_counts[sw];
+        const uint32_t slice_base = scan_slice_base(sw, scan_waves, scan_tiles);
+        const uint32_t W = B.work_counts[LIST_EXP * REINA_MAX_SCAN_WAVES + sw];
         for (uint32_t b0 = 0; b0 < W; b0 += 64) {
             const uint32_t idx = b0 + lane;
             uint4 it = make_uint4(0, 0, 0, 0);
-            if (idx < W) it = items[slice_base + idx];
-            uint32_t nr = it.y & 0xFFu;
+            uint32_t nr = 0;
+            if (idx < W) {
+                // person_expose_others -> get_exposed_people -> get_nr_contacts (main.pyx:247-281,
+                // 936-955,1308-1320): the scan recorded (agent, start-of-day word) of every
+                // infectious, undetected agent; draw its contact COUNT here, 64 agents per wave
+                const uint2 ex = items[slice_base + idx];
+                const uint32_t i = ex.x, w = ex.y;
+                const uint32_t st = RH_STATE(w);
+                const int v = RH_VARIANT(w), sev = RH_SEV(w);
+                const int dayrel = st == RS_INCUBATION ? -(int)RH_DAYS_LEFT(w) : (int)RH_DOI(w);
+                const float inf = S.iot[v][dayrel + 10];
+                const int age = age_of(S.age_start, i, 0, (int)P->nr_ages - 1);
+                float factor = 1.0f;
+                int limit = 100;
+                if (st == RS_ILLNESS && sev != RV_ASYMPTOMATIC) {
+                    factor = 0.5f;
+                    limit = 5;
+                }
+                float z = rp_normal_from_u32(rp_philox(P->k0, P->k1, i, dp.day, RP_P_NRCONTACTS, 0).v[0]);
+                float f = rp_expf(0.5f * z) * S.nrc[age];
+                f *= factor;
+                if (f < 1.0f) f = 1.0f;
+                int n = (int)f - 1;
+                if (n > limit) n = limit;
+                nr = (uint32_t)n;
+                float src_inf = inf;
+                if (sev == RV_ASYMPTOMATIC) src_inf *= d.p_asymptomatic_infection[v];
+                it = make_uint4(i, nr | ((uint32_t)v << 8) | ((uint32_t)age << 16), rp_f2u(src_inf), 0u);
+            }
             // inclusive prefix sum of nr across the wave
             uint32_t inc = nr;
 #pragma unroll
@@ -1430,7 +1303,10 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
     if (lane == 0 && wave_contacts) atomicAdd(&S.n_contacts, (int)wave_contacts);
     __syncthreads();
     if (tid < REINA_NR_PLACES && S.daily[tid]) atomicAdd(&B.counters[SC_IDX(REINA_S_DAILY_CONTACTS + tid)], S.daily[tid]);
-    if (tid == 0 && S.n_contacts) atomicAdd(&B.control[REINA_L_CONTACTS], S.n_contacts);
+    if (tid == 0 && S.n_contacts) {
+        atomicAdd(&B.control[REINA_L_CONTACTS], S.n_contacts);
+        atomicAdd(&B.counters[SC_IDX(REINA_S_EXPOSED_PER_DAY)], S.n_contacts);  // = sum of the counts drawn
+    }
     if (n_shards > 1)
         for (int k = tid; k < REINA_PRESSURE_WORDS; k += CON_THREADS)
             if (S_pressure[k]) atomicAdd(&B.pressure[k], S_pressure[k]);
@@ -1510,12 +1386,19 @@ __global__ __launch_bounds__(256) void k_remote(const DevParams *P, reina_buffer
 // ---------------------------------------------------------------------------------------------
 // k_install: the attempt whose source holds the smallest (priority, id) key per target wins
 // (the reference: first source in rotated scan order, main.pyx:1982-1992) and infects it.
-__global__ void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp,
+                                                 uint32_t scan_waves, uint32_t scan_tiles) {
     __shared__ int32_t new_by_age[REINA_MAX_AGES];
     __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
-    if (B.control[REINA_L_CAND] <= (int)(blockIdx.x * blockDim.x)) return;  // nothing for this workgroup
+    __shared__ int32_t s_cnt[SL_NR][REINA_MAX_AGES];
+    __shared__ int32_t s_infectors, s_infections;
     for (int k = threadIdx.x; k <= REINA_MAX_AGES; k += blockDim.x) s_age_start[k] = P->age_start[k];
+    for (int k = threadIdx.x; k < SL_NR * REINA_MAX_AGES; k += blockDim.x) (&s_cnt[0][0])[k] = 0;
+    if (threadIdx.x == 0) {
+        s_infectors = 0;
+        s_infections = 0;
+    }
     if (threadIdx.x < REINA_MAX_AGES) new_by_age[threadIdx.x] = 0;
     if (threadIdx.x < REINA_MAX_VARIANTS) new_by_variant[threadIdx.x] = 0;
     __syncthreads();
@@ -1530,7 +1413,59 @@ __global__ void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp)
         const int32_t src = (cd.y & RP_REMOTE_SRC) ? -1 : (int32_t)cd.y;
         install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, src, 0, dp.testing_mode, new_by_age, new_by_variant);
     }
+    // the scan's deferred work, one scanning wave's slices per workgroup turn:
+    const uint32_t cap = P->max_work_items;
+    const uint2 *l_ill = reinterpret_cast<const uint2 *>(B.work_items) + cap;
+    const uint2 *l_book = reinterpret_cast<const uint2 *>(B.scan_lists) + cap;
+    for (uint32_t sw = blockIdx.x; sw < scan_waves; sw += gridDim.x) {
+        const uint32_t base = scan_slice_base(sw, scan_waves, scan_tiles);
+        // symptom onsets (person_become_ill)
+        const uint32_t n_ill = B.work_counts[LIST_ILL * REINA_MAX_SCAN_WAVES + sw];
+        for (uint32_t j = threadIdx.x; j < n_ill; j += blockDim.x) {
+            const uint2 r = l_ill[base + j];
+            become_ill(P, B, dp, r.x, r.y);
+        }
+        // bookkeeping: R statistics (main.pyx:1969-1972) and the per-age counters of agents who
+        // recovered or died at home today (Population.recover / die, main.pyx:1584-1623)
+        const uint32_t n_bk = B.work_counts[LIST_BOOK * REINA_MAX_SCAN_WAVES + sw];
+        for (uint32_t j0 = 0; j0 < n_bk; j0 += blockDim.x) {
+            const uint32_t j = j0 + threadIdx.x;
+            int ni = 0, cr = 0;
+            if (j < n_bk) {
+                const uint2 r = l_book[base + j];
+                if (r.y == EVX_COUNT_R) {
+                    cr = 1;
+                    ni = B.n_infected[r.x];
+                } else {
+                    const int age = age_of(s_age_start, r.x, 0, (int)P->nr_ages - 1);
+                    atomicAdd(&s_cnt[SL_INFECTED][age], -1);
+                    if (r.y == EVX_RECOVERED_HOME) {
+                        atomicAdd(&s_cnt[SL_RECOVERED][age], 1);
+                    } else {
+                        atomicAdd(&s_cnt[SL_DEAD][age], 1);
+                        atomicAdd(&s_cnt[SL_NHD][age], 1);
+                    }
+                }
+            }
+            const int tc = wave_sum(cr), tn = wave_sum(ni);
+            if ((threadIdx.x & 63) == 0 && tc) {
+                atomicAdd(&s_infectors, tc);
+                if (tn) atomicAdd(&s_infections, tn);
+            }
+        }
+    }
     flush_new_infections(B, new_by_age, new_by_variant, (int)blockDim.x);
+    for (int k = threadIdx.x; k < SL_NR * REINA_MAX_AGES; k += blockDim.x) {
+        int32_t v = (&s_cnt[0][0])[k];
+        if (v) {
+            const int map[SL_NR] = {REINA_C_INFECTED, REINA_C_RECOVERED, REINA_C_DEAD, REINA_C_NON_HOSPITAL_DEATHS};
+            atomicAdd(&B.counters[CNT_IDX(map[k / REINA_MAX_AGES], k % REINA_MAX_AGES)], v);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (s_infectors) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTORS)], s_infectors);
+        if (s_infections) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTIONS)], s_infections);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1605,6 +1540,12 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     const uint64_t shard_seed = rp_shard_seed(cfg->seed, e->cfg.shard_rank);
     e->h_params.k0 = (uint32_t)shard_seed;
     e->h_params.k1 = (uint32_t)(shard_seed >> 32);
+    for (uint32_t v = 0; v < REINA_MAX_VARIANTS; v++) {
+        uint32_t m = 0;
+        for (int k = 0; k < REINA_IOT_LEN; k++)
+            if (disease->infectiousness_over_time[v][k] != 0.0f) m |= 1u << k;
+        e->h_params.iot_mask[v] = m;
+    }
     e->h_params.n_shards = e->cfg.n_shards;
     e->h_params.shard_rank = e->cfg.shard_rank;
     e->h_params.mirror_slots = cfg->mirror_slots ? cfg->mirror_slots : 64;
@@ -1720,7 +1661,7 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
     } else {
         hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SCAN_THREADS), 0, s, e->d_params, e->buf, dp);
     }
-    hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s, e->d_params, e->buf, dp);
+    hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s, e->d_params, e->buf, dp, scan_waves, scan_tiles);
     {
         uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
         if (con_blocks > 512) con_blocks = 512;
@@ -1739,7 +1680,14 @@ int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) 
     const uint32_t N = e->cfg.n_agents;
     if (e->cfg.n_shards > 1)
         hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256)), dim3(256), 0, s, e->d_params, e->buf, dp);
-    hipLaunchKernelGGL(k_install, dim3(grid_for(N / 64 + 1, 256, 512)), dim3(256), 0, s, e->d_params, e->buf, dp);
+    {
+        const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
+        uint32_t scan_blocks = (scan_tiles / 4u + SCAN_WAVES - 1) / SCAN_WAVES;
+        if (scan_blocks < 1) scan_blocks = 1;
+        if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
+        hipLaunchKernelGGL(k_install, dim3(grid_for(N / 64 + 1, 256, 512)), dim3(256), 0, s, e->d_params, e->buf, dp,
+                           scan_blocks * SCAN_WAVES, scan_tiles);
+    }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
