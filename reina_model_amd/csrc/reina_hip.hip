@@ -851,24 +851,38 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
     const int tid = threadIdx.x;
     __shared__ int s_pre[HOSP_THREADS + 1], s_admit[2];
     // collect the scan's hospital events: exclusive prefix over the per-wave counts
-    const uint32_t per_w = (scan_waves + HOSP_THREADS - 1) / HOSP_THREADS;
+    const uint32_t per_w = (scan_waves + HOSP_THREADS - 1) / HOSP_THREADS;  // <= 8
+    uint32_t cnts[8];
     int mine = 0;
-    for (uint32_t k = 0; k < per_w; k++) {
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
         const uint32_t sw = tid * per_w + k;
-        if (sw < scan_waves) mine += (int)B.work_counts[LIST_EV * REINA_MAX_SCAN_WAVES + sw];
+        cnts[k] = (k < per_w && sw < scan_waves) ? B.work_counts[LIST_EV * REINA_MAX_SCAN_WAVES + sw] : 0u;
+        mine += (int)cnts[k];
     }
-    s_pre[tid + 1] = mine;
-    if (tid == 0) {
-        s_pre[0] = 0;
-        s_admit[0] = 0;
-        s_admit[1] = 0;
-    }
-    __syncthreads();
-    for (int off = 1; off < HOSP_THREADS; off <<= 1) {
-        int vv = s_pre[tid + 1];
-        if (tid + 1 > off) vv += s_pre[tid + 1 - off];
+    {
+        __shared__ int s_wsum[HOSP_THREADS / 64];
+        const int lane = tid & 63, wv = tid >> 6;
+        int inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wsum[wv] = inc;
+        if (tid == 0) {
+            s_admit[0] = 0;
+            s_admit[1] = 0;
+        }
         __syncthreads();
-        s_pre[tid + 1] = vv;
+        int before = 0, total = 0;
+        for (int w2 = 0; w2 < HOSP_THREADS / 64; w2++) {
+            int t2 = s_wsum[w2];
+            if (w2 < wv) before += t2;
+            total += t2;
+        }
+        s_pre[tid] = before + inc - mine;  // exclusive prefix of this thread
+        if (tid == 0) s_pre[HOSP_THREADS] = total;
         __syncthreads();
     }
     int M = s_pre[HOSP_THREADS];
@@ -888,10 +902,11 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
     {   // event word = [priority:20][agent:32][type:2]; the priority is a Philox hash of (agent, day)
         const uint2 *l_ev = reinterpret_cast<const uint2 *>(B.scan_lists);
         int pos = s_pre[tid], nh = 0, nt = 0;
-        for (uint32_t k = 0; k < per_w; k++) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
             const uint32_t sw = tid * per_w + k;
-            if (sw >= scan_waves) break;
-            const uint32_t n = B.work_counts[LIST_EV * REINA_MAX_SCAN_WAVES + sw];
+            const uint32_t n = cnts[k];
+            if (n == 0) continue;
             const uint32_t base = scan_slice_base(sw, scan_waves, scan_tiles);
             for (uint32_t j = 0; j < n; j++, pos++) {
                 if (pos >= M) break;
@@ -1413,26 +1428,71 @@ __global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffe
         const int32_t src = (cd.y & RP_REMOTE_SRC) ? -1 : (int32_t)cd.y;
         install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, src, 0, dp.testing_mode, new_by_age, new_by_variant);
     }
-    // the scan's deferred work, one scanning wave's slices per workgroup turn:
+    // the scan's deferred work.  Each wave of this kernel takes up to 8 scanning-wave slices at a
+    // time, loads their counts together and walks the concatenation 64 records at a time, so lanes
+    // stay dense even though a single slice holds only a handful of records.
     const uint32_t cap = P->max_work_items;
     const uint2 *l_ill = reinterpret_cast<const uint2 *>(B.work_items) + cap;
     const uint2 *l_book = reinterpret_cast<const uint2 *>(B.scan_lists) + cap;
-    for (uint32_t sw = blockIdx.x; sw < scan_waves; sw += gridDim.x) {
-        const uint32_t base = scan_slice_base(sw, scan_waves, scan_tiles);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves_t = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t sw0 = wave_g * 8u; sw0 < scan_waves; sw0 += waves_t * 8u) {
+        uint32_t c_ill[8], c_bk[8], base[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t sw = sw0 + (uint32_t)k;
+            const bool in = sw < scan_waves;
+            c_ill[k] = in ? B.work_counts[LIST_ILL * REINA_MAX_SCAN_WAVES + sw] : 0u;
+            c_bk[k] = in ? B.work_counts[LIST_BOOK * REINA_MAX_SCAN_WAVES + sw] : 0u;
+            base[k] = scan_slice_base(in ? sw : 0u, scan_waves, scan_tiles);
+        }
+        uint32_t t_ill = 0, t_bk = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            t_ill += c_ill[k];
+            t_bk += c_bk[k];
+        }
         // symptom onsets (person_become_ill)
-        const uint32_t n_ill = B.work_counts[LIST_ILL * REINA_MAX_SCAN_WAVES + sw];
-        for (uint32_t j = threadIdx.x; j < n_ill; j += blockDim.x) {
-            const uint2 r = l_ill[base + j];
-            become_ill(P, B, dp, r.x, r.y);
+        for (uint32_t j0 = 0; j0 < t_ill; j0 += 64u) {
+            uint32_t j = j0 + lane;
+            if (j < t_ill) {
+                uint32_t bsel = base[0];
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (!done) {
+                        if (j < c_ill[k]) {
+                            bsel = base[k];
+                            done = true;
+                        } else {
+                            j -= c_ill[k];
+                        }
+                    }
+                }
+                const uint2 r = l_ill[bsel + j];
+                become_ill(P, B, dp, r.x, r.y);
+            }
         }
         // bookkeeping: R statistics (main.pyx:1969-1972) and the per-age counters of agents who
         // recovered or died at home today (Population.recover / die, main.pyx:1584-1623)
-        const uint32_t n_bk = B.work_counts[LIST_BOOK * REINA_MAX_SCAN_WAVES + sw];
-        for (uint32_t j0 = 0; j0 < n_bk; j0 += blockDim.x) {
-            const uint32_t j = j0 + threadIdx.x;
+        for (uint32_t j0 = 0; j0 < t_bk; j0 += 64u) {
+            uint32_t j = j0 + lane;
             int ni = 0, cr = 0;
-            if (j < n_bk) {
-                const uint2 r = l_book[base + j];
+            if (j < t_bk) {
+                uint32_t bsel = base[0];
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (!done) {
+                        if (j < c_bk[k]) {
+                            bsel = base[k];
+                            done = true;
+                        } else {
+                            j -= c_bk[k];
+                        }
+                    }
+                }
+                const uint2 r = l_book[bsel + j];
                 if (r.y == EVX_COUNT_R) {
                     cr = 1;
                     ni = B.n_infected[r.x];
@@ -1448,7 +1508,7 @@ __global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffe
                 }
             }
             const int tc = wave_sum(cr), tn = wave_sum(ni);
-            if ((threadIdx.x & 63) == 0 && tc) {
+            if (lane == 0 && tc) {
                 atomicAdd(&s_infectors, tc);
                 if (tn) atomicAdd(&s_infections, tn);
             }
