@@ -363,6 +363,7 @@ static void run_testing(Par *e, const reina_day_t *dp) {
                     if (try_queue(e, (uint32_t)c, i, dp)) queue_append(e, nxt, (uint32_t)c);
         }
     }
+    CTL(e, lcur) = 0;
 }
 
 /* HealthcareSystem.vaccinate_people (main.pyx:560-583): oldest first, persistent cursor (agents
@@ -767,8 +768,6 @@ int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
     if (!e->bound) return REINA_E_NOT_BOUND;
     if (dp->history_row) memcpy(dp->history_row, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
     uint32_t import_base = 0;
-    /* the queue processed yesterday becomes today's append target */
-    CTL(e, ((dp->day & 1) ^ 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0) = 0;
     SC(e, REINA_S_DAY) = (int32_t)dp->day + 1;
     SC(e, REINA_S_BEDS) += dp->add_beds;
     SC(e, REINA_S_AVAILABLE_BEDS) += dp->add_beds;

@@ -72,6 +72,13 @@ struct reina_engine {
     Tables h_tables;
     bool testing_ever = false;
     int uniform_meta = 0;
+    // independent kernels of a day run side by side on a second stream
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork1 = nullptr, ev_join1 = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
+    bool join2_pending = false;
+    // measured on MI355X / ROCm 7.2: cross-stream event waits cost more than the overlap wins back
+    // (HUS 0.108 -> 0.127 ms/day, 50 M agents 0.315 -> 0.311), so the second stream stays off
+    bool overlap = false;
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
@@ -416,7 +423,7 @@ __device__ void pro_vaccinate(const DevParams *P, const reina_buffers_t &B, cons
     }
 }
 
-__global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, reina_buffers_t B, reina_day_t dp, int do_post) {
     __shared__ uint8_t placed[PRO_MAX_IMPORTS];
     __shared__ uint32_t s_wave_cnt[PRO_THREADS / 64];
     __shared__ uint32_t s_unplaced;
@@ -435,8 +442,6 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
     __syncthreads();
     if (tid == 0) {
         s_import_base = 0;
-        // the queue processed yesterday becomes today's append target
-        B.control[((dp.day & 1) ^ 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] = 0;
         B.counters[SC_IDX(REINA_S_DAY)] = (int32_t)dp.day + 1;
         B.counters[SC_IDX(REINA_S_BEDS)] += dp.add_beds;
         B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] += dp.add_beds;
@@ -468,10 +473,31 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
         // HealthcareSystem.iterate: ct_cases_per_day = len(queue) (main.pyx:518-519)
         B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] = B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
     }
+    // weekly imports: here, or (two-stream mode) in k_imports_post beside the test-queue kernels;
+    // vaccination follows the test-queue pass in the reference (main.pyx:547-558) and is launched
+    // from k_vaccinate after both.
+    if (do_post) {
+        __syncthreads();
+        pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
+    }
+}
+
+// Population.infect_people_daily (main.pyx:1671-1685): imports that run after init_day's zeroing
+__global__ __launch_bounds__(PRO_THREADS) void k_imports_post(const DevParams *P, reina_buffers_t B, reina_day_t dp,
+                                                              uint32_t import_base) {
+    __shared__ uint8_t placed[PRO_MAX_IMPORTS];
+    __shared__ uint32_t s_unplaced;
+    __shared__ uint32_t s_import_base;
+    __shared__ int32_t new_by_age[REINA_MAX_AGES];
+    __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
+    const int tid = threadIdx.x;
+    if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
+    if (tid < REINA_MAX_AGES) new_by_age[tid] = 0;
+    if (tid < REINA_MAX_VARIANTS) new_by_variant[tid] = 0;
+    if (tid == 0) s_import_base = import_base;
     __syncthreads();
     pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
-    // note: vaccination follows the test-queue pass in the reference (main.pyx:547-558); it only
-    // reads DETECTED bits, so it is launched from k_vaccinate after the k_test_* kernels.
 }
 
 __global__ __launch_bounds__(PRO_THREADS) void k_vaccinate(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
@@ -535,7 +561,7 @@ template <int LEVEL>
 __global__ void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
     const int cur = dp.day & 1, nxt = cur ^ 1;
     const uint32_t *src = LEVEL == 0 ? (cur ? B.queue1 : B.queue0) : B.level1;
-    const int n = LEVEL == 0 ? B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] : B.control[REINA_L_LEVEL1];
+    const int n = LEVEL == 0 ? B.control[cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0] : B.control[REINA_L_LEVEL1];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         uint32_t i = src[k];
         int32_t inf = B.infector[i];
@@ -1525,6 +1551,8 @@ __global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffe
     if (threadIdx.x == 0) {
         if (s_infectors) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTORS)], s_infectors);
         if (s_infections) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTIONS)], s_infections);
+        // today's test queue has been processed (k_test_*): empty it for the day after tomorrow
+        if (blockIdx.x == 0) B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] = 0;
     }
 }
 
@@ -1627,6 +1655,11 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK(hipMalloc(&e->d_tables, sizeof(Tables)));
     HIP_CHECK(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice));
+    HIP_CHECK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork1, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&e->ev_join1, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)con_shared_bytes(REINA_MAX_AGES, REINA_MAX_SHARDS)));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hospital), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1638,6 +1671,14 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
 int reina_destroy(reina_engine_t *e) {
     if (!e) return REINA_E_INVALID;
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    if (e->s2) {
+        hipStreamSynchronize(e->s2);
+        hipStreamDestroy(e->s2);
+        hipEventDestroy(e->ev_fork1);
+        hipEventDestroy(e->ev_join1);
+        hipEventDestroy(e->ev_fork2);
+        hipEventDestroy(e->ev_join2);
+    }
     hipFree(e->d_params);
     hipFree(e->d_tables);
     delete e;
@@ -1695,16 +1736,29 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
     hipStream_t s = (hipStream_t)stream;
     const reina_day_t dp = *day;
     const uint32_t N = e->cfg.n_agents;
-    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
+    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp, e->overlap ? 0 : 1);
     if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
+    uint32_t n_pre = 0, n_post = 0;
+    for (uint32_t b = 0; b < dp.n_import_batches; b++)
+        (dp.import_batches[b].pre_init ? n_pre : n_post) += dp.import_batches[b].count;
+    hipStream_t s2 = e->overlap ? e->s2 : s;
     if (e->testing_ever) {
-        const int g = grid_for(N / 64 + 1, 256, 256);
-        hipLaunchKernelGGL(k_test_detect, dim3(g), dim3(256), 0, s, e->d_params, e->buf, dp);
-        if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            hipLaunchKernelGGL(k_test_trace<0>, dim3(g), dim3(256), 0, s, e->d_params, e->buf, dp);
-            hipLaunchKernelGGL(k_test_trace<1>, dim3(g), dim3(256), 0, s, e->d_params, e->buf, dp);
+        // test queue + tracing touch only infected / removed agents and the detection counters;
+        // weekly imports touch only never-infected agents: run them side by side
+        if (e->overlap) {
+            HIP_CHECK(hipEventRecord(e->ev_fork1, s));
+            HIP_CHECK(hipStreamWaitEvent(s2, e->ev_fork1, 0));
         }
+        const int g = grid_for(N / 64 + 1, 256, 256);
+        hipLaunchKernelGGL(k_test_detect, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
+        if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
+            hipLaunchKernelGGL(k_test_trace<0>, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
+            hipLaunchKernelGGL(k_test_trace<1>, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
+        }
+        if (e->overlap) HIP_CHECK(hipEventRecord(e->ev_join1, s2));
     }
+    if (n_post && e->overlap) hipLaunchKernelGGL(k_imports_post, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp, n_pre);
+    if (e->testing_ever && e->overlap) HIP_CHECK(hipStreamWaitEvent(s, e->ev_join1, 0));
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
     // scan geometry: tiles of 512 agents; every wave gets >= 4 tiles when the population is small
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
@@ -1721,7 +1775,16 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
     } else {
         hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SCAN_THREADS), 0, s, e->d_params, e->buf, dp);
     }
-    hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s, e->d_params, e->buf, dp, scan_waves, scan_tiles);
+    // bed / ICU events (one workgroup, latency-bound) run beside the contact kernel (whole chip)
+    if (e->overlap) {
+        HIP_CHECK(hipEventRecord(e->ev_fork2, s));
+        HIP_CHECK(hipStreamWaitEvent(s2, e->ev_fork2, 0));
+    }
+    hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s2, e->d_params, e->buf, dp, scan_waves, scan_tiles);
+    if (e->overlap) {
+        HIP_CHECK(hipEventRecord(e->ev_join2, s2));
+        e->join2_pending = true;
+    }
     {
         uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
         if (con_blocks > 512) con_blocks = 512;
@@ -1738,6 +1801,10 @@ int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) 
     hipStream_t s = (hipStream_t)stream;
     const reina_day_t dp = *day;
     const uint32_t N = e->cfg.n_agents;
+    if (e->join2_pending) {  // installs read list flags the hospital kernel may clear: join first
+        HIP_CHECK(hipStreamWaitEvent(s, e->ev_join2, 0));
+        e->join2_pending = false;
+    }
     if (e->cfg.n_shards > 1)
         hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256)), dim3(256), 0, s, e->d_params, e->buf, dp);
     {
