@@ -557,13 +557,34 @@ __device__ __forceinline__ bool try_queue(const DevParams *P, const reina_buffer
 
 // level 0 (from the detected queue, accepted candidates also go to the level-1 list) and
 // level 1 (from the level-1 list, no further recursion)
+// Level 0 also performs the detection of its queue entry (k_test_detect's job) in the same pass:
+// every member of today's queue carries QUEUED until its single store replaces it with DETECTED,
+// so a tracer can never re-queue another member, whichever of the two runs first.
 template <int LEVEL>
-__global__ void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(256) void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+    __shared__ int32_t s_det[REINA_MAX_AGES];
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     const int cur = dp.day & 1, nxt = cur ^ 1;
     const uint32_t *src = LEVEL == 0 ? (cur ? B.queue1 : B.queue0) : B.level1;
     const int n = LEVEL == 0 ? B.control[cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0] : B.control[REINA_L_LEVEL1];
+    if (n <= (int)(blockIdx.x * blockDim.x)) return;
+    if (LEVEL == 0) {
+        if (threadIdx.x <= REINA_MAX_AGES) s_age_start[threadIdx.x] = P->age_start[threadIdx.x];
+        if (threadIdx.x < REINA_MAX_AGES) s_det[threadIdx.x] = 0;
+        __syncthreads();
+    }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         uint32_t i = src[k];
+        uint32_t wi;
+        if (LEVEL == 0) {
+            const uint32_t w0 = B.hot[i];
+            if (w0 & RH_DETECTED) set_problem(B.counters, 7 /* WRONG_STATE */);
+            wi = (w0 & ~RH_QUEUED) | RH_DETECTED;
+            B.hot[i] = wi;
+            atomicAdd(&s_det[age_of(s_age_start, i, 0, (int)P->nr_ages - 1)], 1);
+        } else {
+            wi = ld_hot(&B.hot[i]);
+        }
         int32_t inf = B.infector[i];
         if (inf >= 0 && try_queue(P, B, (uint32_t)inf, i, dp)) {
             queue_append(P, B, nxt, (uint32_t)inf);
@@ -572,7 +593,7 @@ __global__ void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t 
                 if (pos < P->max_queue) B.level1[pos] = (uint32_t)inf; else set_problem(B.counters, REINA_PROBLEM_QUEUE_OVERFLOW);
             }
         }
-        if (ld_hot(&B.hot[i]) & RH_HASLIST) {
+        if (wi & RH_HASLIST) {
             for (int32_t c = B.first_infectee[i]; c >= 0; c = B.next_sibling[c]) {
                 if (try_queue(P, B, (uint32_t)c, i, dp)) {
                     queue_append(P, B, nxt, (uint32_t)c);
@@ -582,6 +603,13 @@ __global__ void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t 
                     }
                 }
             }
+        }
+    }
+    if (LEVEL == 0) {
+        __syncthreads();
+        if (threadIdx.x < REINA_MAX_AGES && s_det[threadIdx.x]) {
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
+            atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
         }
     }
 }
@@ -1443,9 +1471,14 @@ __global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffe
     if (threadIdx.x < REINA_MAX_AGES) new_by_age[threadIdx.x] = 0;
     if (threadIdx.x < REINA_MAX_VARIANTS) new_by_variant[threadIdx.x] = 0;
     __syncthreads();
-    const int C = min(B.control[REINA_L_CAND], (int)P->max_candidates);
+    // even workgroups install the winning candidates, odd ones walk the scan's deferred lists:
+    // two latency-bound jobs side by side instead of one after the other
+    const uint32_t half = gridDim.x >> 1;                 // grid is even (host)
+    const bool do_cand = (blockIdx.x & 1u) == 0u;
+    const uint32_t blk = blockIdx.x >> 1;
+    const int C = do_cand ? min(B.control[REINA_L_CAND], (int)P->max_candidates) : 0;
     const uint4 *cand = reinterpret_cast<const uint4 *>(B.candidates);
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < C; k += gridDim.x * blockDim.x) {
+    for (int k = blk * blockDim.x + threadIdx.x; k < C; k += half * blockDim.x) {
         uint4 cd = cand[k];
         if (cd.x == 0xFFFFFFFFu) continue;  // hole left by the chunked reservation
         if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
@@ -1461,8 +1494,8 @@ __global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffe
     const uint2 *l_ill = reinterpret_cast<const uint2 *>(B.work_items) + cap;
     const uint2 *l_book = reinterpret_cast<const uint2 *>(B.scan_lists) + cap;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves_t = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t sw0 = wave_g * 8u; sw0 < scan_waves; sw0 += waves_t * 8u) {
+    const uint32_t wave_g = (blk * blockDim.x + threadIdx.x) >> 6, waves_t = (half * blockDim.x) >> 6;
+    for (uint32_t sw0 = do_cand ? scan_waves : wave_g * 8u; sw0 < scan_waves; sw0 += waves_t * 8u) {
         uint32_t c_ill[8], c_bk[8], base[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1750,10 +1783,11 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
             HIP_CHECK(hipStreamWaitEvent(s2, e->ev_fork1, 0));
         }
         const int g = grid_for(N / 64 + 1, 256, 256);
-        hipLaunchKernelGGL(k_test_detect, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            hipLaunchKernelGGL(k_test_trace<0>, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
+            hipLaunchKernelGGL(k_test_trace<0>, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);  // detects + traces
             hipLaunchKernelGGL(k_test_trace<1>, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
+        } else {
+            hipLaunchKernelGGL(k_test_detect, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
         }
         if (e->overlap) HIP_CHECK(hipEventRecord(e->ev_join1, s2));
     }
@@ -1812,7 +1846,8 @@ int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) 
         uint32_t scan_blocks = (scan_tiles / 4u + SCAN_WAVES - 1) / SCAN_WAVES;
         if (scan_blocks < 1) scan_blocks = 1;
         if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
-        hipLaunchKernelGGL(k_install, dim3(grid_for(N / 64 + 1, 256, 512)), dim3(256), 0, s, e->d_params, e->buf, dp,
+        int ig = grid_for(N / 64 + 1, 256, 512) * 2;  // even: candidates / deferred lists
+        hipLaunchKernelGGL(k_install, dim3(ig), dim3(256), 0, s, e->d_params, e->buf, dp,
                            scan_blocks * SCAN_WAVES, scan_tiles);
     }
     HIP_CHECK(hipGetLastError());
