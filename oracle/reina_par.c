@@ -248,9 +248,28 @@ static void level1_append(Par *e, uint32_t idx) {
 }
 
 /* ---------------------------------------------------------------- imports (rounds) */
-/* Population.infect_people / get_import_infection_person (main.pyx:1632-1665), parallel form:
- * 10 rounds; in a round every unplaced import proposes one target; a susceptible target goes to
- * the lowest import number proposing it; the rest try again next round. */
+/* Population.infect_people / get_import_infection_person (main.pyx:1632-1665), parallel form.
+ * Each import owns up to 10 tries (draws keyed by import number and try).  In a round every
+ * unplaced import walks its remaining tries to the first one that hits a never-infected agent
+ * and proposes it; a target proposed by several imports goes to the lowest import number, the
+ * others go on with their next try in the next round (they would have met an infected agent). */
+static int import_target(Par *e, const reina_day_t *dp, uint32_t j, uint32_t k, uint32_t *t_out) {
+    const reina_disease_t *d = &e->dis;
+    rp_u4 r = rp_philox(e->k0, e->k1, j, dp->day, RP_P_IMPORT, k);
+    float p = rp_uniform24(r.v[0]);
+    uint32_t c = d->n_import_classes - 1;
+    for (uint32_t q = 0; q < d->n_import_classes; q++)
+        if (p <= d->import_class_cum[q]) {
+            c = q;
+            break;
+        }
+    uint32_t start = (uint32_t)e->cfg.age_start[d->import_class_min_age[c]];
+    uint32_t end = (uint32_t)e->cfg.age_start[d->import_class_max_age[c] + 1];
+    if (end <= start) return 0;
+    *t_out = start + r.v[1] % (end - start);
+    return 1;
+}
+
 static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *import_base) {
     uint32_t total = 0;
     for (uint32_t b = 0; b < dp->n_import_batches; b++)
@@ -258,32 +277,28 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
     if (!total) return;
     uint32_t *variant = (uint32_t *)malloc(sizeof(uint32_t) * total);
     uint32_t *target = (uint32_t *)malloc(sizeof(uint32_t) * total);
-    uint8_t *placed = (uint8_t *)calloc(total, 1);
+    uint8_t *next_try = (uint8_t *)calloc(total, 1); /* 0..10; 255 = placed */
     uint32_t n = 0;
     for (uint32_t b = 0; b < dp->n_import_batches; b++)
         if ((int)dp->import_batches[b].pre_init == pre_init)
             for (uint32_t k = 0; k < dp->import_batches[b].count; k++) variant[n++] = dp->import_batches[b].variant;
-    const reina_disease_t *d = &e->dis;
     for (uint32_t round = 0; round < 10; round++) {
-        /* propose */
+        uint32_t proposals = 0;
         for (uint32_t j = 0; j < total; j++) {
             target[j] = 0xFFFFFFFFu;
-            if (placed[j]) continue;
-            rp_u4 r = rp_philox(e->k0, e->k1, *import_base + j, dp->day, RP_P_IMPORT, round);
-            float p = rp_uniform24(r.v[0]);
-            uint32_t c = d->n_import_classes - 1;
-            for (uint32_t k = 0; k < d->n_import_classes; k++)
-                if (p <= d->import_class_cum[k]) {
-                    c = k;
+            if (next_try[j] == 255) continue;
+            uint32_t k = next_try[j];
+            for (; k < 10; k++) {
+                uint32_t t;
+                if (import_target(e, dp, *import_base + j, k, &t) && RH_STATE(e->buf.hot[t]) == RS_SUSCEPTIBLE) {
+                    target[j] = t;
                     break;
                 }
-            uint32_t start = (uint32_t)e->cfg.age_start[d->import_class_min_age[c]];
-            uint32_t end = (uint32_t)e->cfg.age_start[d->import_class_max_age[c] + 1];
-            if (end <= start) continue;
-            uint32_t t = start + r.v[1] % (end - start);
-            if (RH_STATE(e->buf.hot[t]) == RS_SUSCEPTIBLE) target[j] = t;
+            }
+            next_try[j] = (uint8_t)(k < 10 ? k + 1 : 10);
+            if (target[j] != 0xFFFFFFFFu) proposals++;
         }
-        /* grant: lowest import number per target (claim keys carry the import number) */
+        if (!proposals) break;
         for (uint32_t j = 0; j < total; j++) {
             if (target[j] == 0xFFFFFFFFu) continue;
             uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
@@ -294,16 +309,16 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
             uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
             if (e->buf.claim[target[j]] == key) {
                 install_infection(e, target[j], dp->day, variant[j], -1, 1, dp->testing_mode);
-                placed[j] = 1;
+                next_try[j] = 255;
             }
         }
     }
     for (uint32_t j = 0; j < total; j++)
-        if (!placed[j]) SC(e, REINA_S_UNABLE_TO_IMPORT) += 1;
+        if (next_try[j] != 255) SC(e, REINA_S_UNABLE_TO_IMPORT) += 1;
     *import_base += total;
     free(variant);
     free(target);
-    free(placed);
+    free(next_try);
 }
 
 /* ---------------------------------------------------------------- testing queue + tracing */

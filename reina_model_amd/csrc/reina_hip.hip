@@ -277,9 +277,29 @@ __global__ void k_init(const DevParams *P, reina_buffers_t B, int32_t beds, int3
 #define PRO_THREADS 1024
 #define PRO_MAX_IMPORTS 16384
 
-// Population.infect_people / get_import_infection_person (main.pyx:1632-1665), parallel form:
-// 10 rounds; every unplaced import proposes one target per round; a susceptible target goes to the
-// lowest import number proposing it (atomicMin on the claim word); the rest retry next round.
+// Population.infect_people / get_import_infection_person (main.pyx:1632-1665), parallel form.
+// Each import owns up to 10 tries (draws keyed by import number and try).  In a round every
+// unplaced import walks its remaining tries to the first one that hits a never-infected agent and
+// proposes it (atomicMin claim); a target proposed by several imports goes to the lowest import
+// number, the others go on with their next try in the next round.  Usually one round.
+__device__ __forceinline__ bool import_target(const DevParams *P, const int32_t *s_age_start, const reina_day_t &dp,
+                                              uint32_t j, uint32_t k, uint32_t *t_out) {
+    const reina_disease_t &d = P->dis;
+    rp_u4 r = rp_philox(P->k0, P->k1, j, dp.day, RP_P_IMPORT, k);
+    float p = rp_uniform24(r.v[0]);
+    uint32_t c = d.n_import_classes - 1;
+    for (uint32_t q = 0; q < d.n_import_classes; q++)
+        if (p <= d.import_class_cum[q]) {
+            c = q;
+            break;
+        }
+    uint32_t start = (uint32_t)s_age_start[d.import_class_min_age[c]];
+    uint32_t end = (uint32_t)s_age_start[d.import_class_max_age[c] + 1];
+    if (end <= start) return false;
+    *t_out = start + r.v[1] % (end - start);
+    return true;
+}
+
 __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, int pre_init,
                             uint32_t *import_base, uint8_t *placed, uint32_t *s_unplaced,
                             int32_t *new_by_age, int32_t *new_by_variant, const int32_t *s_age_start) {
@@ -291,50 +311,38 @@ __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const 
         if (threadIdx.x == 0) set_problem(B.counters, REINA_PROBLEM_WORK_OVERFLOW);
         total = PRO_MAX_IMPORTS;
     }
+    // placed[j]: next try (0..10), 255 = placed; bit 7 of (try | 0x80) marks "proposed this round"
     for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS) placed[j] = 0;
     __syncthreads();
-    const reina_disease_t &d = P->dis;
+    const uint32_t base = *import_base;
     for (uint32_t round = 0; round < 10; round++) {
-        // propose + claim
+        int proposals = 0;
         for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS) {
-            if (placed[j]) continue;
-            rp_u4 r = rp_philox(P->k0, P->k1, *import_base + j, dp.day, RP_P_IMPORT, round);
-            float p = rp_uniform24(r.v[0]);
-            uint32_t c = d.n_import_classes - 1;
-            for (uint32_t k = 0; k < d.n_import_classes; k++)
-                if (p <= d.import_class_cum[k]) {
-                    c = k;
+            if (placed[j] == 255) continue;
+            uint32_t k = placed[j], t = 0;
+            bool found = false;
+            for (; k < 10; k++) {
+                if (import_target(P, s_age_start, dp, base + j, k, &t) && RH_STATE(ld_hot(&B.hot[t])) == RS_SUSCEPTIBLE) {
+                    found = true;
                     break;
                 }
-            uint32_t start = (uint32_t)s_age_start[d.import_class_min_age[c]];
-            uint32_t end = (uint32_t)s_age_start[d.import_class_max_age[c] + 1];
-            placed[j] = 2;  // proposing nothing
-            if (end <= start) continue;
-            uint32_t t = start + r.v[1] % (end - start);
-            if (RH_STATE(ld_hot(&B.hot[t])) == RS_SUSCEPTIBLE) {
-                atomicMin((unsigned long long *)&B.claim[t],
-                          (unsigned long long)rp_order_key(dp.day, 0xFFFFFu - round, j));
-                placed[j] = 3;  // proposed
+            }
+            if (found) {
+                atomicMin((unsigned long long *)&B.claim[t], (unsigned long long)rp_order_key(dp.day, 0xFFFFFu - round, j));
+                placed[j] = (uint8_t)(0x80u | k);  // proposed try k
+                proposals++;
+            } else {
+                placed[j] = 10;
             }
         }
-        __syncthreads();
-        // grant + install
+        if (__syncthreads_or(proposals) == 0) break;
         for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS) {
-            uint8_t st = placed[j];
-            if (st == 1) continue;
-            placed[j] = 0;
-            if (st != 3) continue;
-            rp_u4 r = rp_philox(P->k0, P->k1, *import_base + j, dp.day, RP_P_IMPORT, round);
-            float p = rp_uniform24(r.v[0]);
-            uint32_t c = d.n_import_classes - 1;
-            for (uint32_t k = 0; k < d.n_import_classes; k++)
-                if (p <= d.import_class_cum[k]) {
-                    c = k;
-                    break;
-                }
-            uint32_t start = (uint32_t)s_age_start[d.import_class_min_age[c]];
-            uint32_t end = (uint32_t)s_age_start[d.import_class_max_age[c] + 1];
-            uint32_t t = start + r.v[1] % (end - start);
+            const uint8_t st = placed[j];
+            if (st == 255 || !(st & 0x80u)) continue;
+            const uint32_t k = st & 0x7Fu;
+            uint32_t t = 0;
+            import_target(P, s_age_start, dp, base + j, k, &t);
+            placed[j] = (uint8_t)(k + 1);
             if (ld_claim(&B.claim[t]) == rp_order_key(dp.day, 0xFFFFFu - round, j)) {
                 // variant of import j: walk the batches of this phase
                 uint32_t variant = 0, acc = 0;
@@ -348,20 +356,16 @@ __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const 
                 }
                 uint32_t w = ld_hot(&B.hot[t]);
                 install_infection(P, B, s_age_start, t, w, dp.day, variant, -1, 1, dp.testing_mode, new_by_age, new_by_variant);
-                placed[j] = 1;
+                placed[j] = 255;
             }
         }
         __syncthreads();
-        // every import placed? (workgroup-uniform)
-        int left = 0;
-        for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS) left += placed[j] != 1;
-        if (__syncthreads_or(left) == 0) break;
     }
     if (threadIdx.x == 0) *s_unplaced = 0;
     __syncthreads();
     uint32_t mine = 0;
     for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS)
-        if (placed[j] != 1) mine++;
+        if (placed[j] != 255) mine++;
     if (mine) atomicAdd(s_unplaced, mine);
     __syncthreads();
     if (threadIdx.x == 0) {
