@@ -907,80 +907,108 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
     __shared__ int32_t s_cnt[HL_NR][REINA_MAX_AGES];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     const int tid = threadIdx.x;
-    __shared__ int s_pre[HOSP_THREADS + 1], s_admit[2];
-    // collect the scan's hospital events: exclusive prefix over the per-wave counts
+    __shared__ int s_wsum[4][HOSP_THREADS / 64];
+    __shared__ int s_tot[4];
+    const uint2 *l_ev = reinterpret_cast<const uint2 *>(B.scan_lists);
+    // pass 1: count this thread's events by type (its <= 8 scan slices)
     const uint32_t per_w = (scan_waves + HOSP_THREADS - 1) / HOSP_THREADS;  // <= 8
     uint32_t cnts[8];
-    int mine = 0;
+    int mine[4] = {0, 0, 0, 0};
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
         const uint32_t sw = tid * per_w + k;
         cnts[k] = (k < per_w && sw < scan_waves) ? B.work_counts[LIST_EV * REINA_MAX_SCAN_WAVES + sw] : 0u;
-        mine += (int)cnts[k];
     }
-    {
-        __shared__ int s_wsum[HOSP_THREADS / 64];
-        const int lane = tid & 63, wv = tid >> 6;
-        int inc = mine;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
+    for (uint32_t k = 0; k < 8; k++) {
+        if (cnts[k] == 0) continue;
+        const uint32_t base = scan_slice_base(tid * per_w + k, scan_waves, scan_tiles);
+        for (uint32_t j = 0; j < cnts[k]; j++) {
+            const uint32_t ty = l_ev[base + j].y & 3u;
+            mine[0] += ty == 0;
+            mine[1] += ty == 1;
+            mine[2] += ty == 2;
+            mine[3] += ty == 3;
         }
-        if (lane == 63) s_wsum[wv] = inc;
-        if (tid == 0) {
-            s_admit[0] = 0;
-            s_admit[1] = 0;
+    }
+    // exclusive prefix per type over the workgroup (wave shuffles + 16 wave totals)
+    int excl[4];
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int ty = 0; ty < 4; ty++) {
+            int inc = mine[ty];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                int o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            if (lane == 63) s_wsum[ty][wv] = inc;
+            excl[ty] = inc - mine[ty];
         }
         __syncthreads();
-        int before = 0, total = 0;
-        for (int w2 = 0; w2 < HOSP_THREADS / 64; w2++) {
-            int t2 = s_wsum[w2];
-            if (w2 < wv) before += t2;
-            total += t2;
+#pragma unroll
+        for (int ty = 0; ty < 4; ty++) {
+            int before = 0, total = 0;
+            for (int w2 = 0; w2 < HOSP_THREADS / 64; w2++) {
+                int t2 = s_wsum[ty][w2];
+                if (w2 < wv) before += t2;
+                total += t2;
+            }
+            excl[ty] += before;
+            if (tid == 0) s_tot[ty] = total;
         }
-        s_pre[tid] = before + inc - mine;  // exclusive prefix of this thread
-        if (tid == 0) s_pre[HOSP_THREADS] = total;
         __syncthreads();
     }
-    int M = s_pre[HOSP_THREADS];
+    const int nH = s_tot[EV_HOSPITALIZE], nT = s_tot[EV_TO_ICU], nW = s_tot[EV_RELEASE_WARD], nI = s_tot[EV_RELEASE_ICU];
+    int M = nH + nT + nW + nI;
     if (M > REINA_MAX_HOSP_EVENTS) {
         if (tid == 0) set_problem(B.counters, REINA_PROBLEM_HOSPITAL_OVERFLOW);
-        M = REINA_MAX_HOSP_EVENTS;
+        return;
     }
     if (M == 0) return;
-    int M2 = 1;
-    while (M2 < M) M2 <<= 1;
-    // an admission that finds no free bed / ICU unit is marked in bit 63 of its event word
     const int b0 = B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)], c0 = B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)];
-    for (int k = tid; k < M2; k += HOSP_THREADS) ev[k] = ~0ull;
+    // Only events that touch a resource that can run out today need their order: beds are touched
+    // by HOSPITALIZE / TO_ICU / RELEASE_WARD, ICU units by TO_ICU / RELEASE_ICU.  Events are laid out
+    // by type so that the order-relevant ones form a prefix [0, R) of the LDS array.
+    const bool beds_bind = b0 < nH, icu_bind = c0 < nT;
+    const bool ordered = beds_bind || icu_bind;
+    int off_ty[4];
+    int R;
+    if (icu_bind && !beds_bind) {        // [T][I][H][W]
+        off_ty[EV_TO_ICU] = 0; off_ty[EV_RELEASE_ICU] = nT; off_ty[EV_HOSPITALIZE] = nT + nI; off_ty[EV_RELEASE_WARD] = nT + nI + nH;
+        R = nT + nI;
+    } else {                             // [T][H][W][I]
+        off_ty[EV_TO_ICU] = 0; off_ty[EV_HOSPITALIZE] = nT; off_ty[EV_RELEASE_WARD] = nT + nH; off_ty[EV_RELEASE_ICU] = nT + nH + nW;
+        R = (beds_bind && !icu_bind) ? nT + nH + nW : M;
+    }
+    if (!ordered) R = 0;
+    int M2 = 1;  // bitonic size: the relevant prefix padded to a power of two
+    while (M2 < R) M2 <<= 1;
     for (int k = tid; k < HL_NR * REINA_MAX_AGES; k += HOSP_THREADS) (&s_cnt[0][0])[k] = 0;
     if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
-    __syncthreads();
-    {   // event word = [priority:20][agent:32][type:2]; the priority is a Philox hash of (agent, day)
-        const uint2 *l_ev = reinterpret_cast<const uint2 *>(B.scan_lists);
-        int pos = s_pre[tid], nh = 0, nt = 0;
+    {   // pass 2: place. event word = [priority:20][agent:32][type:2]; priority = Philox(agent, day)
+        int pos[4] = {off_ty[0] + excl[0], off_ty[1] + excl[1], off_ty[2] + excl[2], off_ty[3] + excl[3]};
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t sw = tid * per_w + k;
-            const uint32_t n = cnts[k];
-            if (n == 0) continue;
-            const uint32_t base = scan_slice_base(sw, scan_waves, scan_tiles);
-            for (uint32_t j = 0; j < n; j++, pos++) {
-                if (pos >= M) break;
+            if (cnts[k] == 0) continue;
+            const uint32_t base = scan_slice_base(tid * per_w + k, scan_waves, scan_tiles);
+            for (uint32_t j = 0; j < cnts[k]; j++) {
                 const uint2 r = l_ev[base + j];
                 const uint64_t prio = rp_priority20(P->k0, P->k1, r.x, dp.day);
-                ev[pos] = (prio << 34) | ((uint64_t)r.x << 2) | (uint64_t)r.y;
-                nh += r.y == EV_HOSPITALIZE;
-                nt += r.y == EV_TO_ICU;
+                const uint32_t ty = r.y & 3u;
+                const int p2 = ty == 0 ? pos[0]++ : ty == 1 ? pos[1]++ : ty == 2 ? pos[2]++ : pos[3]++;
+                ev[p2] = (prio << 34) | ((uint64_t)r.x << 2) | (uint64_t)ty;
             }
         }
-        if (nh) atomicAdd(&s_admit[0], nh);
-        if (nt) atomicAdd(&s_admit[1], nt);
     }
     __syncthreads();
-    const bool ordered = !(b0 >= s_admit[0] && c0 >= s_admit[1]);
     if (ordered) {
+        // sort the prefix [0, M2): entries past R (other types, or past M) compare as +infinity
+        for (int k = tid; k < M2; k += HOSP_THREADS)
+            if (k >= R && k < M) ev[k] |= 1ull << 62;
+        for (int k = M + tid; k < M2; k += HOSP_THREADS) ev[k] = ~0ull;
+        __syncthreads();
         for (int size = 2; size <= M2; size <<= 1) {
             for (int strd = size >> 1; strd > 0; strd >>= 1) {
                 for (int k = tid; k < M2; k += HOSP_THREADS) {
@@ -997,9 +1025,11 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
                 __syncthreads();
             }
         }
+        for (int k = tid; k < M2 && k < M; k += HOSP_THREADS) ev[k] &= ~(1ull << 62);
+        __syncthreads();
         // chunked scan: thread t owns events [t*per, (t+1)*per)
-        const int per = (M + HOSP_THREADS - 1) / HOSP_THREADS;
-        const int lo = tid * per, hi = min(M, lo + per);
+        const int per = (R + HOSP_THREADS - 1) / HOSP_THREADS;
+        const int lo = min(R, tid * per), hi = min(R, lo + per);
         SatFn fb, fc;
         fb.a = fc.a = 0;
         fb.m = fc.m = SAT_NEG;
@@ -1046,8 +1076,12 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, r
             if (!ok) ev[k] |= 1ull << 63;
         }
         if (tid == HOSP_THREADS - 1) {
-            s_b = sat_apply(s_fb[HOSP_THREADS - 1], b0);
-            s_c = sat_apply(s_fc[HOSP_THREADS - 1], c0);
+            int fb_ = sat_apply(s_fb[HOSP_THREADS - 1], b0), fc_ = sat_apply(s_fc[HOSP_THREADS - 1], c0);
+            // events outside the ordered prefix touch a resource that cannot run out: plain sums
+            if (icu_bind && !beds_bind) fb_ += nW - nH;
+            if (beds_bind && !icu_bind) fc_ += nI;
+            s_b = fb_;
+            s_c = fc_;
         }
     } else {
         if (tid == 0) {
