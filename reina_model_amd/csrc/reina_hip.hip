@@ -1918,6 +1918,12 @@ int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream) {
 int reina_profile_enable(reina_engine_t *e, int enable) {
     if (!e) return REINA_E_INVALID;
     e->profile = enable != 0;
+    // create the timing events up front: hipEventCreate inside the timed region costs microseconds each
+    while (e->profile && e->ev_pool.size() < 2048) {
+        hipEvent_t ev;
+        HIP_CHECK(hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
     return REINA_OK;
 }
 
