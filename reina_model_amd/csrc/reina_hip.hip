@@ -1832,9 +1832,9 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
     if (n_post && e->overlap) hipLaunchKernelGGL(k_imports_post, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp, n_pre);
     if (e->testing_ever && e->overlap) HIP_CHECK(hipStreamWaitEvent(s, e->ev_join1, 0));
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
-    // scan geometry: tiles of 512 agents; every wave gets >= 4 tiles when the population is small
+    // scan geometry: tiles of 512 agents, as many waves as tiles (small populations) up to 8192
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-    uint32_t scan_blocks = (scan_tiles / 4u + SCAN_WAVES - 1) / SCAN_WAVES;
+    uint32_t scan_blocks = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;  // one 512-agent tile per wave until the grid cap
     if (scan_blocks < 1) scan_blocks = 1;
     if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
     const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
@@ -1881,7 +1881,7 @@ int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) 
         hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256)), dim3(256), 0, s, e->d_params, e->buf, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-        uint32_t scan_blocks = (scan_tiles / 4u + SCAN_WAVES - 1) / SCAN_WAVES;
+        uint32_t scan_blocks = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;  // one 512-agent tile per wave until the grid cap
         if (scan_blocks < 1) scan_blocks = 1;
         if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
         int ig = grid_for(N / 64 + 1, 256, 512) * 2;  // even: candidates / deferred lists

@@ -200,6 +200,8 @@ class Context:
         beds, ICU units and import / vaccination quotas given here are the GLOBAL ones."""
         from .sharding import split_count, split_population
         self.comm = comm
+        # testing aid: take the begin / all-reduce / end path even with a single shard
+        self.always_collective = bool(comm is not None and getattr(comm, 'always_collective', False))
         self.shard_rank = comm.rank if comm is not None else 0
         self.n_shards = comm.world if comm is not None else 1
         self._split = lambda x: split_count(x, self.shard_rank, self.n_shards)
@@ -433,7 +435,7 @@ class Context:
     # ------------------------------------------------------------------ day stepping
     # main.pyx:2011-2018
     def _step(self, d):
-        if self.n_shards == 1:
+        if self.n_shards == 1 and not self.always_collective:
             self.engine.step_day(d)
         else:
             # the ONLY per-day collective: sum the cross-shard infection pressure (2048 int32)
@@ -468,7 +470,7 @@ class Context:
                     self.engine.run_days(pending)
                     pending = []
                 self._upload_tables()
-            if self.n_shards == 1:
+            if self.n_shards == 1 and not self.always_collective:
                 pending.append(d)
             else:
                 self._step(d)
@@ -476,7 +478,7 @@ class Context:
         if pending:
             self.engine.run_days(pending)
         if record_history:
-            if self.n_shards > 1:
+            if self.n_shards > 1 or self.always_collective:
                 out = self._reduce_counter_rows(hist, days)
             else:
                 out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
@@ -498,7 +500,7 @@ class Context:
 
     def _read_counters_global(self):
         c = self.engine.read_counters()
-        if self.n_shards == 1:
+        if self.n_shards == 1 and not self.always_collective:
             return c
         return self._reduce_counter_rows_host(c)
 

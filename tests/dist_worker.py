@@ -34,8 +34,9 @@ def main():
     ages = datasets.scaled_population(total)
     factory = None if backend == 'nccl' else par_backend.par_engine_factory
     device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', rank)) if backend == 'nccl' else 'cpu'
-    ctx = simulation.make_context(v, age_counts=ages, seed=21, engine_factory=factory, device=device,
-                                  comm=sharding.TorchComm())
+    comm = sharding.TorchComm()
+    comm.always_collective = True  # exercise begin / all-reduce / end even when world == 1
+    ctx = simulation.make_context(v, age_counts=ages, seed=21, engine_factory=factory, device=device, comm=comm)
     hist = ctx.run(days)
     final = ctx.generate_state()
     if rank == 0:

@@ -43,3 +43,13 @@ def test_population_split_is_a_partition():
         assert np.array_equal(np.sum(parts, axis=0), ages)
         assert max(p.sum() for p in parts) - min(p.sum() for p in parts) <= len(ages)
         assert sum(sharding.split_count(2600, r, world) for r in range(world)) == 2600
+
+
+@pytest.mark.gpu
+def test_nccl_single_rank_exercises_the_collective_path():
+    """RCCL path on the one GPU of the test box: init_process_group('nccl'), the per-day pressure
+    all-reduce on an HBM int32 tensor, host counter blocks staged through HBM.  world_size 1, so
+    the result must equal the CPU oracle's unsharded run (checked by the worker)."""
+    r = _launch(1, 'nccl', 80, 40000)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'DIST_OK world=1' in r.stdout
