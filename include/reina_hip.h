@@ -160,7 +160,9 @@ typedef struct {
     int32_t *control;         /* [REINA_L_NR] */
     uint32_t *work_items;     /* [max_work_items * 4] (src, nr | variant << 8 | age << 16, src_inf bits, pad);
                                  max_work_items >= n_agents + 1024 */
-    uint32_t *candidates;     /* [max_candidates * 4] (target, src, variant, prio); target 0xFFFFFFFF = hole */
+    uint32_t *candidates;     /* [max_candidates * 4] (target, src, variant, prio); target 0xFFFFFFFF = hole.
+                                 [0, max_work_items): per-slice regions; above: candidates realised from
+                                 cross-shard pressure. max_candidates >= max_work_items + expected remote */
     uint32_t *queue0;         /* [max_queue] testing queue, even days */
     uint32_t *queue1;         /* [max_queue] testing queue, odd days */
     uint32_t *level1;         /* [max_queue] contact-tracing level-1 work list */
@@ -173,9 +175,10 @@ typedef struct {
                                  a day-tagged hash sample of this shard's OUTGOING cross-shard attempts,
                                  from which an incoming infection takes a local stand-in infector
                                  ("mirror attribution", reina_model_amd/sharding.py) */
-    uint32_t *work_counts;    /* [4 * REINA_MAX_SCAN_WAVES] entries written by each scanning wave into its
-                                 private slice of the four scan lists (no global append counter):
-                                 exposure candidates, symptom onsets, hospital events, bookkeeping */
+    uint32_t *work_counts;    /* [5 * REINA_MAX_SCAN_WAVES] entries per scanning-wave slice of the per-slice
+                                 lists (no global append counters): exposure candidates, symptom onsets,
+                                 hospital events, bookkeeping (written by the scan) and infection
+                                 candidates (written by the contact kernel for the slice's sources) */
     uint32_t *scan_lists;     /* [4 * max_work_items] two lists of (agent, kind) pairs written by the
                                  scan: hospital events, then bookkeeping (R statistics, home
                                  recoveries / deaths). The other two lists live in work_items. */

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void k_test_trace(const DevParams *P, reina_bu
 #define SCAN_THREADS 256
 #define SCAN_WAVES (SCAN_THREADS / 64)
 enum { SL_INFECTED = 0, SL_RECOVERED, SL_DEAD, SL_NHD, SL_NR };
-enum { LIST_EXP = 0, LIST_ILL = 1, LIST_EV = 2, LIST_BOOK = 3 };
+enum { LIST_EXP = 0, LIST_ILL = 1, LIST_EV = 2, LIST_BOOK = 3, LIST_CAND = 4 };
 enum { EVX_COUNT_R = 4, EVX_RECOVERED_HOME = 5, EVX_DIED_HOME = 6 };
 
 // entries of scan wave `sw` start here in every list (a wave's slice is as large as the number
@@ -1238,11 +1238,12 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
     const uint32_t n_shards = P->n_shards, shard_rank = P->shard_rank;
     const uint2 *items = reinterpret_cast<const uint2 *>(B.work_items);
     const uint32_t total_waves = gridDim.x * CON_WAVES;
-    // candidate slots are reserved CAND_CHUNK at a time (one atomic per chunk, not per hit)
-    uint32_t cbase = 0, cused = CAND_CHUNK;
     uint32_t wave_contacts = 0;
     for (uint32_t sw = blockIdx.x * CON_WAVES + wave; sw < scan_waves; sw += total_waves) {
         const uint32_t slice_base = scan_slice_base(sw, scan_waves, scan_tiles);
+        // successful attempts of this slice's sources go to the slice's own candidate region
+        const uint32_t slice_cap = (sw + 1 < scan_waves ? scan_slice_base(sw + 1, scan_waves, scan_tiles) : P->max_work_items) - slice_base;
+        uint32_t n_cand = 0;
         const uint32_t W = B.work_counts[LIST_EXP * REINA_MAX_SCAN_WAVES + sw];
         for (uint32_t b0 = 0; b0 < W; b0 += 64) {
             const uint32_t idx = b0 + lane;
@@ -1374,38 +1375,22 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
                     uint64_t pm_ = __ballot(place == pl);
                     if (pm_ && lane == 0) atomicAdd(&S.daily[pl], (int)__popcll(pm_));
                 }
-                // candidate records
+                // candidate records: ballot slots in the slice's region, no atomics
                 const uint64_t hm = __ballot(hit);
                 if (hm) {
-                    const uint32_t need = (uint32_t)__popcll(hm);
-                    if (cused + need > CAND_CHUNK) {
-                        // close the current chunk with holes, open a new one
-                        if (cused < CAND_CHUNK && (uint32_t)lane < CAND_CHUNK - cused && cbase + cused + lane < P->max_candidates)
-                            reinterpret_cast<uint4 *>(B.candidates)[cbase + cused + lane] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-                        if (cused + 64 < CAND_CHUNK && (uint32_t)lane + 64 < CAND_CHUNK - cused && cbase + cused + 64 + lane < P->max_candidates)
-                            reinterpret_cast<uint4 *>(B.candidates)[cbase + cused + 64 + lane] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-                        uint32_t nb = 0;
-                        if (lane == 0) nb = (uint32_t)atomicAdd(&B.control[REINA_L_CAND], CAND_CHUNK);
-                        cbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-                        cused = 0;
-                    }
                     if (hit) {
-                        uint32_t pos = cbase + cused + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-                        if (pos >= P->max_candidates)
+                        const uint32_t pos = n_cand + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                        if (pos >= slice_cap)
                             set_problem(B.counters, REINA_PROBLEM_CANDIDATE_OVERFLOW);
                         else
-                            reinterpret_cast<uint4 *>(B.candidates)[pos] = cand;
+                            reinterpret_cast<uint4 *>(B.candidates)[slice_base + pos] = cand;
                     }
-                    cused += need;
+                    n_cand += (uint32_t)__popcll(hm);
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
-    }
-    // holes in the last open chunk
-    if (cused < CAND_CHUNK) {
-        for (uint32_t k = cused + lane; k < CAND_CHUNK; k += 64)
-            if (cbase + k < P->max_candidates) reinterpret_cast<uint4 *>(B.candidates)[cbase + k] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+        if (lane == 0) B.work_counts[LIST_CAND * REINA_MAX_SCAN_WAVES + sw] = n_cand < slice_cap ? n_cand : slice_cap;
     }
     if (lane == 0 && wave_contacts) atomicAdd(&S.n_contacts, (int)wave_contacts);
     __syncthreads();
@@ -1441,9 +1426,17 @@ __global__ __launch_bounds__(256) void k_remote(const DevParams *P, reina_buffer
         s_pre[cells] = acc;
     }
     __syncthreads();
-    const uint32_t total = s_pre[cells];
+    uint32_t total = s_pre[cells];
+    const uint32_t room = P->max_candidates - P->max_work_items;
+    if (total > room) {
+        if (tid == 0 && blockIdx.x == 0) set_problem(B.counters, REINA_PROBLEM_CANDIDATE_OVERFLOW);
+        total = room;
+    }
+    if (tid == 0 && blockIdx.x == 0) B.control[REINA_L_CAND] = (int)total;  // records in the remote region
+    uint4 *rcand = reinterpret_cast<uint4 *>(B.candidates) + P->max_work_items;
     const reina_disease_t &d = P->dis;
     for (uint32_t idx = blockIdx.x * blockDim.x + tid; idx < total; idx += gridDim.x * blockDim.x) {
+        rcand[idx] = make_uint4(0xFFFFFFFFu, 0, 0, 0);  // hole unless the attempt succeeds below
         uint32_t lo = 0, hi = cells - 1;  // cell with s_pre[cell] <= idx < s_pre[cell+1]
         while (lo < hi) {
             uint32_t mid = (lo + hi + 1) >> 1;
@@ -1481,12 +1474,7 @@ __global__ __launch_bounds__(256) void k_remote(const DevParams *P, reina_buffer
                 }
         }
         atomicMin((unsigned long long *)&B.claim[t], (unsigned long long)rp_order_key(dp.day, prio, src));
-        uint32_t pos = wave_alloc(&B.control[REINA_L_CAND]);
-        if (pos >= P->max_candidates) {
-            set_problem(B.counters, REINA_PROBLEM_CANDIDATE_OVERFLOW);
-            continue;
-        }
-        reinterpret_cast<uint4 *>(B.candidates)[pos] = make_uint4(t, src, v, prio);
+        rcand[idx] = make_uint4(t, src, v, prio);
     }
 }
 
@@ -1514,16 +1502,56 @@ __global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffe
     const uint32_t half = gridDim.x >> 1;                 // grid is even (host)
     const bool do_cand = (blockIdx.x & 1u) == 0u;
     const uint32_t blk = blockIdx.x >> 1;
-    const int C = do_cand ? min(B.control[REINA_L_CAND], (int)P->max_candidates) : 0;
     const uint4 *cand = reinterpret_cast<const uint4 *>(B.candidates);
-    for (int k = blk * blockDim.x + threadIdx.x; k < C; k += half * blockDim.x) {
-        uint4 cd = cand[k];
-        if (cd.x == 0xFFFFFFFFu) continue;  // hole left by the chunked reservation
-        if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
-        uint32_t w = ld_hot(&B.hot[cd.x]);
-        if (RH_STATE(w) != RS_SUSCEPTIBLE) continue;  // duplicate record of the same winner
-        const int32_t src = (cd.y & RP_REMOTE_SRC) ? -1 : (int32_t)cd.y;
-        install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, src, 0, dp.testing_mode, new_by_age, new_by_variant);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_g = (blk * blockDim.x + threadIdx.x) >> 6, waves_t = (half * blockDim.x) >> 6;
+    if (do_cand) {
+        // per-slice candidate regions written by k_contacts: 8 slices at a time, 64 records per step
+        for (uint32_t sw0 = wave_g * 8u; sw0 < scan_waves; sw0 += waves_t * 8u) {
+            uint32_t c_n[8], base[8], tot = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t sw = sw0 + (uint32_t)k;
+                const bool in = sw < scan_waves;
+                c_n[k] = in ? B.work_counts[LIST_CAND * REINA_MAX_SCAN_WAVES + sw] : 0u;
+                base[k] = scan_slice_base(in ? sw : 0u, scan_waves, scan_tiles);
+                tot += c_n[k];
+            }
+            for (uint32_t j0 = 0; j0 < tot; j0 += 64u) {
+                uint32_t j = j0 + lane;
+                if (j >= tot) continue;
+                uint32_t bsel = base[0];
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (!done) {
+                        if (j < c_n[k]) {
+                            bsel = base[k];
+                            done = true;
+                        } else {
+                            j -= c_n[k];
+                        }
+                    }
+                }
+                const uint4 cd = cand[bsel + j];
+                if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
+                uint32_t w = ld_hot(&B.hot[cd.x]);
+                if (RH_STATE(w) != RS_SUSCEPTIBLE) continue;  // duplicate record of the same winner
+                install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode, new_by_age, new_by_variant);
+            }
+        }
+        // candidates realised from cross-shard pressure (k_remote), indexed above the slice regions
+        const int C = P->n_shards > 1 ? B.control[REINA_L_CAND] : 0;
+        const uint4 *rcand = cand + P->max_work_items;
+        for (int k = blk * blockDim.x + threadIdx.x; k < C; k += half * blockDim.x) {
+            const uint4 cd = rcand[k];
+            if (cd.x == 0xFFFFFFFFu) continue;  // attempt that did not get through
+            if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
+            uint32_t w = ld_hot(&B.hot[cd.x]);
+            if (RH_STATE(w) != RS_SUSCEPTIBLE) continue;
+            const int32_t src = (cd.y & RP_REMOTE_SRC) ? -1 : (int32_t)cd.y;
+            install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, src, 0, dp.testing_mode, new_by_age, new_by_variant);
+        }
     }
     // the scan's deferred work.  Each wave of this kernel takes up to 8 scanning-wave slices at a
     // time, loads their counts together and walks the concatenation 64 records at a time, so lanes
@@ -1531,8 +1559,6 @@ __global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffe
     const uint32_t cap = P->max_work_items;
     const uint2 *l_ill = reinterpret_cast<const uint2 *>(B.work_items) + cap;
     const uint2 *l_book = reinterpret_cast<const uint2 *>(B.scan_lists) + cap;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_g = (blk * blockDim.x + threadIdx.x) >> 6, waves_t = (half * blockDim.x) >> 6;
     for (uint32_t sw0 = do_cand ? scan_waves : wave_g * 8u; sw0 < scan_waves; sw0 += waves_t * 8u) {
         uint32_t c_ill[8], c_bk[8], base[8];
 #pragma unroll
