@@ -244,6 +244,12 @@ int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);
 int reina_profile_enable(reina_engine_t *e, int enable);
 int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_launches,
                        double *all_ms_total);
+/* replaces Context.sample(what, age, severity) (main.pyx:2047-2101): n draws of one per-agent
+ * quantity with the engine's samplers; host-only, needs no engine and no GPU. `what`: 0
+ * contacts_per_day, 1 symptom_severity, 2 incubation_period, 3 illness_period,
+ * 4 hospitalization_period, 5 icu_period, 6 onset_to_removed_period; severity < 0 = None */
+int reina_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,
+                 float nr_contacts_of_age, int n, int32_t *out);
 const char *reina_last_error(void);
 int reina_abi_version(void);
 

@@ -21,6 +21,7 @@
 
 #include "../include/reina_hip.h"
 #include "../reina_model_amd/csrc/reina_prims.h"
+#include "../reina_model_amd/csrc/reina_sample.h"
 
 typedef struct {
     reina_config_t cfg;
@@ -63,6 +64,12 @@ static int age_of(const Par *e, uint32_t i) {
 }
 
 int par_abi_version(void) { return 1; }
+
+/* Context.sample: the shared host-side sampler (utility, not part of the day step) */
+int par_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,
+               float nr_contacts_of_age, int n, int32_t *out) {
+    return reina_sample_impl(disease, seed, what, age, severity, nr_contacts_of_age, n, out);
+}
 
 int par_create(const reina_config_t *cfg, const reina_disease_t *disease, Par **out) {
     if (cfg->nr_ages > REINA_MAX_AGES || cfg->nr_variants > REINA_MAX_VARIANTS) return REINA_E_INVALID;

@@ -29,6 +29,7 @@
 
 #include "../../include/reina_hip.h"
 #include "reina_prims.h"
+#include "reina_sample.h"
 
 #define CNT_IDX(c, age) ((c) * REINA_MAX_AGES + (age))
 #define SC_IDX(s) (REINA_C_NR * REINA_MAX_AGES + (s))
@@ -1692,6 +1693,11 @@ static void resolve_profile(reina_engine *e) {
 extern "C" {
 
 int reina_abi_version(void) { return 1; }
+
+int reina_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,
+                 float nr_contacts_of_age, int n, int32_t *out) {
+    return reina_sample_impl(disease, seed, what, age, severity, nr_contacts_of_age, n, out);
+}
 const char *reina_last_error(void) { return g_last_error.c_str(); }
 
 int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, reina_engine_t **out) {

@@ -44,7 +44,7 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 32
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'upload_contact_tables',
-                 'step_day', 'step_day_begin', 'step_day_end', 'run_days', 'read_counters', 'profile_enable', 'profile_read',
+                 'step_day', 'step_day_begin', 'step_day_end', 'run_days', 'sample', 'read_counters', 'profile_enable', 'profile_read',
                  'last_error', 'abi_version')
 
 
@@ -131,6 +131,8 @@ def bind_abi(lib, prefix):
     f['step_day_end'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp]
     f['read_counters'].argtypes = [vp, vp, vp]
+    f['sample'].argtypes = [ctypes.POINTER(Disease), ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                            ctypes.c_float, ctypes.c_int, vp]
     f['profile_enable'].argtypes = [vp, ctypes.c_int]
     f['profile_read'].argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                                   ctypes.POINTER(ctypes.c_double)]
@@ -267,6 +269,12 @@ class Engine:
     def read_counters(self):
         out = np.zeros(COUNTER_WORDS, dtype=np.int32)
         self._check(self.f['read_counters'](self._h, out.ctypes.data, self.alloc.stream()), 'read_counters')
+        return out
+
+    def sample(self, disease, seed, what, age, severity, nrc, n):
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self.f['sample'](ctypes.byref(disease), int(seed) & 0xFFFFFFFFFFFFFFFF, int(what), int(age),
+                                     int(severity), float(nrc), int(n), out.ctypes.data), 'sample')
         return out
 
     def profile_enable(self, on=True):

@@ -241,6 +241,9 @@ class Context:
 
         disease, self.variant_names = build_disease_struct(
             disease_params, nr_ages, population_params['imported_infection_ages'])
+        self._disease = disease
+        self._seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
+        self._sample_calls = 0
         self.nr_variants = len(self.variant_names)
 
         cfg = _eng.Config()
@@ -555,6 +558,21 @@ class Context:
         counters = self._read_counters_global()
         self._raise_on_problem(counters)
         return self.state_from_counters(counters)
+
+    # main.pyx:2047-2101
+    SAMPLE_KINDS = ('contacts_per_day', 'symptom_severity', 'incubation_period', 'illness_period',
+                    'hospitalization_period', 'icu_period', 'onset_to_removed_period')
+
+    def sample(self, what, age, severity=None, sample_size=10000):
+        """10 000 draws of one per-agent quantity with the engine's samplers (host-side; each call
+        advances a private stream like the reference advances its RandomPool)."""
+        if what not in self.SAMPLE_KINDS:
+            raise Exception('unknown sample type. supported: %s' % ', '.join(self.SAMPLE_KINDS))
+        sev = -1 if severity is None else STR_TO_SEVERITY[severity]
+        nrc = np.float32(self.contact_matrix.tables.nr_contacts_by_age[age])
+        self._sample_calls += 1
+        seed = (self._seed * 0x9E3779B97F4A7C15 + self._sample_calls) & 0xFFFFFFFFFFFFFFFF
+        return self.engine.sample(self._disease, seed, self.SAMPLE_KINDS.index(what), age, sev, nrc, sample_size)
 
     # main.pyx:1859-1866
     def get_population_stats(self, what):

@@ -141,3 +141,32 @@ def test_simulate_individuals_frame_contract():
     with pytest.raises(simulation.ExecutionInterrupted):
         simulation.simulate_individuals(v, step_callback=lambda d: False, age_counts=datasets.scaled_population(8000),
                                         engine_factory=par_backend.par_engine_factory)
+
+
+def test_context_sample_matches_reference_distributions():
+    """Context.sample() (main.pyx:2047-2101) with the engine's own samplers vs the 10 000-draw
+    samples recorded from the reference: same support, mean within 4 standard errors (+2 %)."""
+    import os
+    from golden_util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'samples.npz'))
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ctx = simulation.make_context(v, age_counts=z['age_counts'], seed=4321, interventions=[],
+                                  engine_factory=par_backend.par_engine_factory)
+    n = 0
+    for key in z.files:
+        if key == 'age_counts' or key.startswith('chain77'):
+            continue
+        what, age, sev = key.split('|')
+        ref = z[key].astype(np.float64)
+        got = ctx.sample(what, int(age), sev or None).astype(np.float64)
+        assert got.shape == ref.shape
+        se = np.sqrt(ref.var() / len(ref) + got.var() / len(got))
+        assert abs(got.mean() - ref.mean()) <= 4 * se + 0.02 * abs(ref.mean()) + 1e-9, (key, got.mean(), ref.mean())
+        assert got.min() >= 0 and got.max() <= max(ref.max() * 3, 4)
+        if what == 'symptom_severity':
+            for s in range(5):
+                assert abs((got == s).mean() - (ref == s).mean()) < 0.02, (key, s)
+        n += 1
+    assert n == 31
+    with pytest.raises(Exception):
+        ctx.sample('infectiousness', 30)

@@ -60,10 +60,23 @@ def _run_and_compare(variables, ages, seed, days, interventions=None, chunk=None
     gpu, cpu = _pair(variables, ages, seed, interventions)
     done = 0
     chunk = chunk or days
+    from reina_model_amd.model import SimulationFailed
     while done < days:
         n = min(chunk, days - done)
-        hg = gpu.run(n)
-        hc = cpu.run(n)
+        failed = []
+        for ctx in (gpu, cpu):
+            try:
+                h = ctx.run(n)
+            except SimulationFailed as e:  # the reference's own failure modes (e.g. 'Wrong state', quirk Q8)
+                failed.append(str(e))
+                h = None
+            if ctx is gpu:
+                hg = h
+            else:
+                hc = h
+        if failed:
+            assert len(failed) == 2 and failed[0] == failed[1], failed
+            break
         if not np.array_equal(hg, hc):
             bad = np.nonzero((hg != hc).any(axis=1))[0][0]
             words = np.nonzero(hg[bad] != hc[bad])[0]
@@ -179,3 +192,62 @@ def test_sharded_population_two_shards_on_one_gpu():
         _assert_state_equal(a, b)
     tot = sharding.reduce_counters(gpu)
     assert tot[eng.C_NAMES.index('all_infected') * eng.MAX_AGES:][:101].sum() > 5000
+
+
+def _random_scenario(rng):
+    """A random but valid scenario: population size, capacities, disease tweaks and a random
+    intervention schedule drawn from every intervention type."""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    total = int(rng.integers(3000, 60000))
+    v['hospital_beds'] = int(rng.integers(0, 40))
+    v['icu_units'] = int(rng.integers(0, 6))
+    v['p_icu_death_no_beds'] = float(rng.choice([100.0, 50.0, 0.0]))
+    v['p_hospital_death_no_beds'] = float(rng.choice([20.0, 100.0, 0.0]))
+    v['infectiousness_multiplier'] = float(rng.uniform(0.3, 1.2))
+    v['variants'] = [{'name': 'b1.1.7', 'infectiousness_multiplier': float(rng.uniform(0.5, 1.5))}]
+    days = int(rng.integers(60, 160))
+    from datetime import date, timedelta
+    d0 = date.fromisoformat(v['start_date'])
+    def day(k):
+        return (d0 + timedelta(days=int(k))).isoformat()
+    ivs = [['import-infections', day(0), int(rng.integers(5, 80))]]
+    places = [None, 'home', 'work', 'school', 'transport', 'leisure', 'other']
+    for _ in range(int(rng.integers(4, 18))):
+        t = rng.choice(['limit-mobility', 'wear-masks', 'import-infections', 'import-infections-weekly',
+                        'test-all-with-symptoms', 'test-only-severe-symptoms', 'test-with-contact-tracing',
+                        'vaccinate', 'build-new-hospital-beds', 'build-new-icu-units'])
+        when = day(rng.integers(0, days))
+        a, b = sorted(int(x) for x in rng.integers(0, 101, size=2))
+        mn = None if rng.random() < 0.4 else a
+        mx = None if rng.random() < 0.4 else b
+        pl = places[int(rng.integers(0, len(places)))]
+        if t == 'limit-mobility':
+            ivs.append([t, when, int(rng.integers(0, 101)), mn, mx, pl])
+        elif t == 'wear-masks':
+            ivs.append([t, when, int(rng.integers(0, 101)), mn, mx, pl])
+        elif t == 'import-infections':
+            ivs.append([t, when, int(rng.integers(1, 60))] + (['b1.1.7'] if rng.random() < 0.3 else []))
+        elif t == 'import-infections-weekly':
+            ivs.append([t, when, int(rng.integers(0, 80)), int(rng.integers(0, 101))])
+        elif t == 'test-only-severe-symptoms':
+            ivs.append([t, when, int(rng.integers(0, 101))])
+        elif t == 'test-with-contact-tracing':
+            ivs.append([t, when, int(rng.integers(0, 101))])
+        elif t == 'vaccinate':
+            ivs.append([t, when, int(rng.integers(0, 3000)), mn, mx])
+        elif t == 'build-new-hospital-beds':
+            ivs.append([t, when, int(rng.integers(1, 20))])
+        elif t == 'build-new-icu-units':
+            ivs.append([t, when, int(rng.integers(1, 4))])
+        else:
+            ivs.append([t, when])
+    return v, datasets.scaled_population(total), days, ivs
+
+
+@pytest.mark.parametrize('case', range(12))
+def test_random_scenarios(case):
+    """Randomised scenarios (all intervention types, odd capacities incl. zero beds / ICU units,
+    random age windows and places): HIP == oracle B bit for bit."""
+    rng = np.random.default_rng(1000 + case)
+    v, ages, days, ivs = _random_scenario(rng)
+    _run_and_compare(v, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40)
