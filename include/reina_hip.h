@@ -237,6 +237,11 @@ int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream);
 /* runs `n_days` consecutive days from an array of day descriptors (the loop of
  * calc/simulation.py:194-270 without the per-day host round trip) */
 int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, void *stream);
+/* the same with the history rows laid out by the library: day k snapshots its counters to
+ * history_base + k * REINA_COUNTER_WORDS (dev pointer, may be NULL); days[k].history_row is
+ * ignored, so ONE descriptor array can drive many engine instances (Monte-Carlo ensembles) */
+int reina_run_days_hist(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, int32_t *history_base,
+                        void *stream);
 /* replaces Context.generate_state's reads (main.pyx:1813-1857): copies the counter block to host
  * (synchronises `stream`) */
 int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);

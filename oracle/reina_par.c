@@ -844,6 +844,16 @@ int par_run_days(Par *e, const reina_day_t *days, uint32_t n, void *stream) {
     return 0;
 }
 
+int par_run_days_hist(Par *e, const reina_day_t *days, uint32_t n, int32_t *history_base, void *stream) {
+    for (uint32_t k = 0; k < n; k++) {
+        reina_day_t d = days[k];
+        d.history_row = history_base ? history_base + (size_t)k * REINA_COUNTER_WORDS : NULL;
+        int rc = par_step_day(e, &d, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int par_read_counters(Par *e, int32_t *out, void *stream) {
     (void)stream;
     memcpy(out, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);

@@ -20,6 +20,7 @@ import numpy as np
 
 PLACES = ('home', 'work', 'school', 'transport', 'leisure', 'other')  # enum order main.pyx:64-70
 PLACE_ALL = 100
+_parsed_cache = {}
 
 
 class ContactTables:
@@ -40,39 +41,52 @@ class ContactMatrix:
     def __init__(self, contacts_per_day, nr_ages):
         """contacts_per_day: iterable of (place_type, participant_age, (cmin, cmax), contacts) or a
         DataFrame with those columns (calc/simulation.py:74-100)."""
+        self.nr_ages = nr_ages
+        key = (id(contacts_per_day), nr_ages)
+        parsed = _parsed_cache.get(key)
+        if parsed is None or parsed[0] is not contacts_per_day:
+            parsed = (contacts_per_day, self._parse(contacts_per_day, nr_ages))
+            _parsed_cache.clear()       # one scenario at a time; keeps the source object alive
+            _parsed_cache[key] = parsed
+        (self._place, self._page, self._cmin, self._cmax, self._contacts, self._rank, self._rows_of_age,
+         self._sorted_rows, self._uniform, self._rows_mat, self._sorted_mat) = parsed[1]
+        self.mobility_factors = []  # [place, min_age, max_age, factor(float32)]
+        self.mobility_factor = np.float32(1.0)
+        self.mobility_factor_changed = False
+        self.mask_probabilities = np.zeros((nr_ages, len(PLACES)), dtype=np.float64)
+        self.tables = None
+        self.generate_contact_probabilities()
+
+    @staticmethod
+    def _parse(contacts_per_day, nr_ages):
+        """Row arrays and the (static) entry order; shared by every ContactMatrix built from the same
+        rows object (ensembles construct many)."""
         if hasattr(contacts_per_day, 'itertuples'):
             rows = [(t.place_type, int(t.participant_age), tuple(t.contact_age), float(t.contacts))
                     for t in contacts_per_day.itertuples()]
         else:
             rows = [(r[0], int(r[1]), tuple(r[2]), float(r[3])) for r in contacts_per_day]
-        self.nr_ages = nr_ages
-        self._place = np.array([PLACES.index(r[0]) for r in rows], dtype=np.int32)
-        self._page = np.array([r[1] for r in rows], dtype=np.int32)
-        self._cmin = np.array([r[2][0] for r in rows], dtype=np.int32)
-        self._cmax = np.array([r[2][1] for r in rows], dtype=np.int32)
-        self._contacts = np.array([r[3] for r in rows], dtype=np.float64)
+        place = np.array([PLACES.index(r[0]) for r in rows], dtype=np.int32)
+        page = np.array([r[1] for r in rows], dtype=np.int32)
+        cmin = np.array([r[2][0] for r in rows], dtype=np.int32)
+        cmax = np.array([r[2][1] for r in rows], dtype=np.int32)
+        contacts = np.array([r[3] for r in rows], dtype=np.float64)
         # sort key of the reference's MultiIndex: (place_type string, contact_age tuple)
         place_rank = {p: i for i, p in enumerate(sorted(PLACES))}
-        self._rank = np.array([place_rank[r[0]] for r in rows], dtype=np.int64)
-        self.mobility_factors = []  # [place, min_age, max_age, factor(float32)]
-        self.mobility_factor = np.float32(1.0)
-        self.mobility_factor_changed = False
-        self.mask_probabilities = np.zeros((nr_ages, len(PLACES)), dtype=np.float64)
+        rank = np.array([place_rank[r[0]] for r in rows], dtype=np.int64)
         # per-age row lists in original order, and the reference's entry order per age
         # (sort_index on (place_type string, contact_age tuple); depends only on the keys)
-        self._rows_of_age = [np.nonzero(self._page == a)[0] for a in range(nr_ages)]
-        self._sorted_rows = []
+        rows_of_age = [np.nonzero(page == a)[0] for a in range(nr_ages)]
+        sorted_rows = []
         for a in range(nr_ages):
-            rows = self._rows_of_age[a]
-            order = np.lexsort((self._cmax[rows], self._cmin[rows], self._rank[rows]))
-            self._sorted_rows.append(rows[order])
-        counts = {len(r) for r in self._rows_of_age}
-        self._uniform = len(counts) == 1 and counts != {0}
-        if self._uniform:
-            self._rows_mat = np.stack(self._rows_of_age)      # [A, E] original order (Kahan order)
-            self._sorted_mat = np.stack(self._sorted_rows)    # [A, E] table order
-        self.tables = None
-        self.generate_contact_probabilities()
+            r = rows_of_age[a]
+            order = np.lexsort((cmax[r], cmin[r], rank[r]))
+            sorted_rows.append(r[order])
+        counts = {len(r) for r in rows_of_age}
+        uniform = len(counts) == 1 and counts != {0}
+        rows_mat = np.stack(rows_of_age) if uniform else None      # [A, E] original order (Kahan order)
+        sorted_mat = np.stack(sorted_rows) if uniform else None    # [A, E] table order
+        return place, page, cmin, cmax, contacts, rank, rows_of_age, sorted_rows, uniform, rows_mat, sorted_mat
 
     # main.pyx:1250-1266
     def set_mobility_factor(self, factor, place=None, min_age=None, max_age=None):

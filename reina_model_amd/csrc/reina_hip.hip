@@ -1938,6 +1938,16 @@ int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, 
     return REINA_OK;
 }
 
+int reina_run_days_hist(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, int32_t *history_base, void *stream) {
+    for (uint32_t k = 0; k < n_days; k++) {
+        reina_day_t d = days[k];
+        d.history_row = history_base ? history_base + (size_t)k * REINA_COUNTER_WORDS : nullptr;
+        int rc = reina_step_day(e, &d, stream);
+        if (rc) return rc;
+    }
+    return REINA_OK;
+}
+
 int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream) {
     if (!e || !out_host) return REINA_E_INVALID;
     if (!e->bound) return REINA_E_NOT_BOUND;

@@ -49,12 +49,15 @@ def get_contacts_per_day(country='FI'):
     d = _load()
     if country != d['country']:
         raise KeyError('no bundled contact matrix for country %r' % country)
+    if 'rows' in _cache:
+        return _cache['rows']
     rows = []
     for ci, (cmin, cmax) in enumerate(d['contact_groups']):
         for place, pmin, pmax, vals in d['contact_rows']:
             c = vals[ci]
             for p in range(pmin, pmax + 1):
                 rows.append((place, p, (cmin, cmax), c))
+    _cache['rows'] = rows   # callers treat the list as read-only
     return rows
 
 

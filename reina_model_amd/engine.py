@@ -44,7 +44,7 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 32
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'upload_contact_tables',
-                 'step_day', 'step_day_begin', 'step_day_end', 'run_days', 'sample', 'read_counters', 'profile_enable', 'profile_read',
+                 'step_day', 'step_day_begin', 'step_day_end', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
                  'last_error', 'abi_version')
 
 
@@ -130,6 +130,7 @@ def bind_abi(lib, prefix):
     f['step_day_begin'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['step_day_end'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp]
+    f['run_days_hist'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp, vp]
     f['read_counters'].argtypes = [vp, vp, vp]
     f['sample'].argtypes = [ctypes.POINTER(Disease), ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                             ctypes.c_float, ctypes.c_int, vp]
@@ -265,6 +266,10 @@ class Engine:
     def run_days(self, days):
         arr = (Day * len(days))(*days)
         self._check(self.f['run_days'](self._h, arr, len(days), self.alloc.stream()), 'run_days')
+
+    def run_day_array(self, arr, n, history_ptr):
+        """`arr` is a ctypes (Day * n) array that may be shared between engines."""
+        self._check(self.f['run_days_hist'](self._h, arr, n, history_ptr, self.alloc.stream()), 'run_days_hist')
 
     def read_counters(self):
         out = np.zeros(COUNTER_WORDS, dtype=np.int32)

@@ -294,12 +294,15 @@ class Context:
         self._iv_index = None
 
     # ------------------------------------------------------------------ host helpers
-    def _upload_tables(self):
+    def _packed_tables(self):
         t = self.contact_matrix.tables
         nrc, count, thr, meta, ranges = pack_contact_tables(t, self.nr_ages)
         mask = np.zeros((_eng.MAX_AGES, 8), dtype=np.float32)
         mask[:self.nr_ages, :6] = self.contact_matrix.mask_probabilities.astype(np.float32)
-        self.engine.upload_contact_tables(nrc, count, thr, meta, mask, ranges)
+        return nrc, count, thr, meta, mask, ranges
+
+    def _upload_tables(self):
+        self.engine.upload_contact_tables(*self._packed_tables())
 
     def get_date_for_today(self):
         d = date.fromisoformat(self.start_date)
@@ -453,41 +456,83 @@ class Context:
         self._step(d)
         self.day += 1
 
+    def make_plan(self, days):
+        """Host part of `days` consecutive days, done once: the intervention schedule turned into
+        day descriptors, cut into stretches of unchanged contact tables.  A plan does not depend
+        on the random seed, so one plan can drive every member of a Monte-Carlo ensemble
+        (reina_model_amd/ensemble.py).  Advances this Context's host-side state by `days`."""
+        segments = []   # (packed tables or None, ctypes Day array, n)
+        pending = []
+        tables = None
+        mobility = []
+        for _ in range(days):
+            mobility.append(float(self.contact_matrix.mobility_factor))
+            d, changed = self._build_day(None)
+            if changed:
+                if pending:
+                    segments.append((tables, (_eng.Day * len(pending))(*pending), len(pending)))
+                    pending = []
+                tables = self._packed_tables()
+            pending.append(d)
+            self.day += 1
+        if pending:
+            segments.append((tables, (_eng.Day * len(pending))(*pending), len(pending)))
+        return dict(segments=segments, days=days, mobility_history=mobility)
+
+    def run_plan(self, plan, record_history=True):
+        """Execute a plan made by make_plan (of this Context or of another one with the same
+        scenario).  Returns history[days, COUNTER_WORDS] like run()."""
+        days = plan['days']
+        a = self.engine.alloc
+        hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None
+        base = a.ptr(hist) if record_history else None
+        done = 0
+        for tables, arr, n in plan['segments']:
+            if tables is not None:
+                self.engine.upload_contact_tables(*tables)
+            ptr = base + 4 * _eng.COUNTER_WORDS * done if record_history else None
+            self.engine.run_day_array(arr, n, ptr)
+            done += n
+        self.mobility_history = plan['mobility_history']
+        if record_history:
+            out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
+            self._raise_on_problem(self.engine.read_counters())
+            return out
+        return None
+
     def run(self, days, record_history=True):
         """Run `days` consecutive days with one library call per stretch of unchanged contact
         tables (the loop of calc/simulation.py:194-270 without per-day host round trips).
         Returns history[days, COUNTER_WORDS] (row d = counters BEFORE day d ran) as a host array,
         or None; `self.mobility_history[d]` is the mobility factor generate_state() would have
         reported on that day."""
+        if self.n_shards == 1 and not self.always_collective:
+            return self.run_plan(self.make_plan(days), record_history)
         a = self.engine.alloc
         hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None
         base = a.ptr(hist) if record_history else 0
-        pending = []
         self.mobility_history = []
         for k in range(days):
             ptr = base + 4 * _eng.COUNTER_WORDS * k if record_history else None
             self.mobility_history.append(float(self.contact_matrix.mobility_factor))
             d, changed = self._build_day(ptr)
             if changed:
-                if pending:
-                    self.engine.run_days(pending)
-                    pending = []
                 self._upload_tables()
-            if self.n_shards == 1 and not self.always_collective:
-                pending.append(d)
-            else:
-                self._step(d)
+            self._step(d)
             self.day += 1
-        if pending:
-            self.engine.run_days(pending)
         if record_history:
-            if self.n_shards > 1 or self.always_collective:
-                out = self._reduce_counter_rows(hist, days)
-            else:
-                out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
+            out = self._reduce_counter_rows(hist, days)
             self._raise_on_problem(self._read_counters_global())
             return out
         return None
+
+    def synchronize(self):
+        self._raise_on_problem(self._read_counters_global())
+
+    def _raise_on_problem(self, counters):
+        problem = int(counters[_eng.C_NR * _eng.MAX_AGES + _eng.S_PROBLEM])
+        if problem != 0:
+            raise SimulationFailed(PROBLEM_TO_STR.get(problem, 'Problem %d' % problem))
 
     # ---- sharded state export: counters are additive over shards; problem / day are not
     def _reduce_counter_rows(self, buf, rows):
@@ -517,14 +562,6 @@ class Context:
         local[:, base + _eng.S_PROBLEM] = problem
         local[:, base + _eng.S_DAY] = day
         return local[0]
-
-    def synchronize(self):
-        self._raise_on_problem(self._read_counters_global())
-
-    def _raise_on_problem(self, counters):
-        problem = int(counters[_eng.C_NR * _eng.MAX_AGES + _eng.S_PROBLEM])
-        if problem != 0:
-            raise SimulationFailed(PROBLEM_TO_STR.get(problem, 'Problem %d' % problem))
 
     # ------------------------------------------------------------------ state export
     def state_from_counters(self, counters, mobility_factor=None):
