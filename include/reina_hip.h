@@ -214,6 +214,7 @@ typedef struct {
 } reina_day_t;
 
 typedef struct reina_engine reina_engine_t;
+typedef struct reina_group reina_group_t;
 
 /* replaces Context.__init__ / Population.__init__ / Disease.__init__ (main.pyx:1759-1781,
  * 1354-1450, 868-881) */
@@ -242,6 +243,16 @@ int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, 
  * ignored, so ONE descriptor array can drive many engine instances (Monte-Carlo ensembles) */
 int reina_run_days_hist(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, int32_t *history_base,
                         void *stream);
+/* Monte-Carlo ensembles (the reference: calc/simulation.py:349-385, a process pool over seeds):
+ * a group of identically configured, unsharded engines that differ in their seed is stepped with
+ * ONE launch per phase for all members (member = blockIdx.y), so small populations still fill the
+ * chip.  history_bases: host array of n device pointers (or NULL); member m's row of day k is
+ * history_bases[m] + k * REINA_COUNTER_WORDS. */
+int reina_group_create(reina_engine_t **engines, uint32_t n, reina_group_t **out);
+int reina_group_destroy(reina_group_t *g);
+int reina_group_upload_contact_tables(reina_group_t *g, const reina_contact_tables_t *t, void *stream);
+int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_days, int32_t *const *history_bases,
+                         void *stream);
 /* replaces Context.generate_state's reads (main.pyx:1813-1857): copies the counter block to host
  * (synchronises `stream`) */
 int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);

@@ -854,6 +854,45 @@ int par_run_days_hist(Par *e, const reina_day_t *days, uint32_t n, int32_t *hist
     return 0;
 }
 
+/* group API (include/reina_hip.h: reina_group_*): on the CPU a group is just its members stepped
+ * one after another -- members share nothing, so the result is the same by construction. */
+typedef struct { Par **members; uint32_t n; } ParGroup;
+
+int par_group_create(Par **engines, uint32_t n, ParGroup **out) {
+    if (!engines || !out || n == 0) return REINA_E_INVALID;
+    for (uint32_t k = 0; k < n; k++)
+        if (engines[k]->cfg.n_agents != engines[0]->cfg.n_agents || engines[k]->cfg.n_shards != 1) return REINA_E_INVALID;
+    ParGroup *g = (ParGroup *)calloc(1, sizeof(ParGroup));
+    g->members = (Par **)malloc(sizeof(Par *) * n);
+    memcpy(g->members, engines, sizeof(Par *) * n);
+    g->n = n;
+    *out = g;
+    return 0;
+}
+
+int par_group_destroy(ParGroup *g) {
+    if (!g) return REINA_E_INVALID;
+    free(g->members);
+    free(g);
+    return 0;
+}
+
+int par_group_upload_contact_tables(ParGroup *g, const reina_contact_tables_t *t, void *stream) {
+    for (uint32_t k = 0; k < g->n; k++) {
+        int rc = par_upload_contact_tables(g->members[k], t, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int par_group_run_days(ParGroup *g, const reina_day_t *days, uint32_t n_days, int32_t *const *history_bases, void *stream) {
+    for (uint32_t k = 0; k < g->n; k++) {
+        int rc = par_run_days_hist(g->members[k], days, n_days, history_bases ? history_bases[k] : NULL, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int par_read_counters(Par *e, int32_t *out, void *stream) {
     (void)stream;
     memcpy(out, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);

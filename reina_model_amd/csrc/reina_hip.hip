@@ -61,6 +61,16 @@ struct Tables {  // bigger tables staged into LDS by k_contacts
     uint32_t meta[REINA_MAX_AGES][REINA_MAX_ENTRIES];
 };
 
+// what a kernel needs to know about one engine instance.  Every kernel takes an array of these and
+// works on element blockIdx.y: a single engine launches with grid.y = 1, a Monte-Carlo group of K
+// engines with grid.y = K (one launch per phase for the whole ensemble).
+struct MemberRef {
+    const DevParams *P;
+    const Tables *T;
+    reina_buffers_t B;
+    int32_t *history_base;  // group runs: row k of this member's history is history_base + k * COUNTER_WORDS
+};
+
 static thread_local std::string g_last_error;
 
 struct reina_engine {
@@ -69,6 +79,7 @@ struct reina_engine {
     bool bound = false;
     DevParams *d_params = nullptr;
     Tables *d_tables = nullptr;
+    MemberRef *d_ref = nullptr;   // {d_params, d_tables, buf, no history base} for single-engine launches
     DevParams h_params;
     Tables h_tables;
     bool testing_ever = false;
@@ -232,7 +243,10 @@ __device__ void flush_new_infections(const reina_buffers_t &B, int32_t *new_by_a
 
 // ---------------------------------------------------------------------------------------------
 // k_init: _create_agents / _init_stats (main.pyx:1389-1450)
-__global__ void k_init(const DevParams *P, reina_buffers_t B, int32_t beds, int32_t icu) {
+__global__ void k_init(const MemberRef *M_, int32_t beds, int32_t icu) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     uint32_t N = P->n_agents;
     uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
@@ -428,7 +442,11 @@ __device__ void pro_vaccinate(const DevParams *P, const reina_buffers_t &B, cons
     }
 }
 
-__global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, reina_buffers_t B, reina_day_t dp, int do_post) {
+__global__ __launch_bounds__(PRO_THREADS) void k_prologue(const MemberRef *M_, reina_day_t dp, int do_post, uint32_t hist_slot) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
+    if (mref_.history_base) dp.history_row = mref_.history_base + (size_t)hist_slot * REINA_COUNTER_WORDS;
     __shared__ uint8_t placed[PRO_MAX_IMPORTS];
     __shared__ uint32_t s_wave_cnt[PRO_THREADS / 64];
     __shared__ uint32_t s_unplaced;
@@ -488,8 +506,11 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const DevParams *P, re
 }
 
 // Population.infect_people_daily (main.pyx:1671-1685): imports that run after init_day's zeroing
-__global__ __launch_bounds__(PRO_THREADS) void k_imports_post(const DevParams *P, reina_buffers_t B, reina_day_t dp,
+__global__ __launch_bounds__(PRO_THREADS) void k_imports_post(const MemberRef *M_, reina_day_t dp,
                                                               uint32_t import_base) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     __shared__ uint8_t placed[PRO_MAX_IMPORTS];
     __shared__ uint32_t s_unplaced;
     __shared__ uint32_t s_import_base;
@@ -505,7 +526,10 @@ __global__ __launch_bounds__(PRO_THREADS) void k_imports_post(const DevParams *P
     pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
 }
 
-__global__ __launch_bounds__(PRO_THREADS) void k_vaccinate(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(PRO_THREADS) void k_vaccinate(const MemberRef *M_, reina_day_t dp) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     __shared__ uint32_t s_wave_cnt[PRO_THREADS / 64];
     __shared__ int32_t s_scalar;
     pro_vaccinate(P, B, dp, s_wave_cnt, &s_scalar);
@@ -525,7 +549,10 @@ __device__ __forceinline__ void queue_append(const DevParams *P, const reina_buf
 }
 
 // Q1: every queued test is positive (quirk Q8): clear QUEUED, set DETECTED
-__global__ __launch_bounds__(256) void k_test_detect(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(256) void k_test_detect(const MemberRef *M_, reina_day_t dp) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     __shared__ int32_t s_det[REINA_MAX_AGES];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     if (B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] <= (int)(blockIdx.x * blockDim.x)) return;
@@ -566,7 +593,10 @@ __device__ __forceinline__ bool try_queue(const DevParams *P, const reina_buffer
 // every member of today's queue carries QUEUED until its single store replaces it with DETECTED,
 // so a tracer can never re-queue another member, whichever of the two runs first.
 template <int LEVEL>
-__global__ __launch_bounds__(256) void k_test_trace(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(256) void k_test_trace(const MemberRef *M_, reina_day_t dp) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     __shared__ int32_t s_det[REINA_MAX_AGES];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     const int cur = dp.day & 1, nxt = cur ^ 1;
@@ -757,7 +787,10 @@ __device__ __forceinline__ uint32_t scan_word(const DevParams *P, ScanLists &L, 
     return p_ill ? w : nw;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const MemberRef *M_, reina_day_t dp) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t N = P->n_agents;
     const uint32_t n4 = N >> 2;
@@ -899,8 +932,11 @@ __device__ __forceinline__ SatFn icu_fn(int type) {
 enum { HL_INFECTED = 0, HL_DETECTED, HL_ALL_DETECTED, HL_HOSPITALIZED, HL_IN_WARD, HL_IN_ICU, HL_CUM_ICU,
        HL_DEAD, HL_NHD, HL_RECOVERED, HL_NR };
 
-__global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const DevParams *P, reina_buffers_t B, reina_day_t dp,
+__global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const MemberRef *M_, reina_day_t dp,
                                                            uint32_t scan_waves, uint32_t scan_tiles) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *ev = reinterpret_cast<uint64_t *>(smem);               // [M2]
     __shared__ int s_b, s_c;
@@ -1208,8 +1244,12 @@ static size_t con_shared_bytes(uint32_t nr_ages, uint32_t n_shards) {
     return sizeof(ConShared) + (size_t)nr_ages * REINA_MAX_ENTRIES * 4 + (n_shards > 1 ? REINA_PRESSURE_WORDS * 4 : 0);
 }
 
-__global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, const Tables *T, reina_buffers_t B, reina_day_t dp,
+__global__ __launch_bounds__(CON_THREADS) void k_contacts(const MemberRef *M_, reina_day_t dp,
                                                           uint32_t scan_waves, uint32_t scan_tiles, int uniform_meta) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
+    const Tables *T = mref_.T;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     ConShared &S = *reinterpret_cast<ConShared *>(smem_raw);
     uint32_t (*S_thr)[REINA_MAX_ENTRIES] = reinterpret_cast<uint32_t (*)[REINA_MAX_ENTRIES]>(smem_raw + sizeof(ConShared));
@@ -1410,7 +1450,10 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const DevParams *P, co
 // been summed over all shards by the caller).  Attempt k of cell (range, variant) picks a uniform
 // local agent of the range and applies the target-side part of did_infect, p_sus(age)/psus_max;
 // survivors compete for the target exactly like local contacts (atomicMin claim + candidate).
-__global__ __launch_bounds__(256) void k_remote(const DevParams *P, reina_buffers_t B, reina_day_t dp) {
+__global__ __launch_bounds__(256) void k_remote(const MemberRef *M_, reina_day_t dp) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     __shared__ uint32_t s_pre[REINA_MAX_RANGES * REINA_MAX_VARIANTS + 1];  // exclusive prefix of cell counts
     const int tid = threadIdx.x;
@@ -1482,8 +1525,11 @@ __global__ __launch_bounds__(256) void k_remote(const DevParams *P, reina_buffer
 // ---------------------------------------------------------------------------------------------
 // k_install: the attempt whose source holds the smallest (priority, id) key per target wins
 // (the reference: first source in rotated scan order, main.pyx:1982-1992) and infects it.
-__global__ __launch_bounds__(256) void k_install(const DevParams *P, reina_buffers_t B, reina_day_t dp,
+__global__ __launch_bounds__(256) void k_install(const MemberRef *M_, reina_day_t dp,
                                                  uint32_t scan_waves, uint32_t scan_tiles) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t &B = mref_.B;
     __shared__ int32_t new_by_age[REINA_MAX_AGES];
     __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
@@ -1756,6 +1802,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     e->h_params.max_queue = cfg->max_queue;
     HIP_CHECK(hipMalloc(&e->d_params, sizeof(DevParams)));
     HIP_CHECK(hipMalloc(&e->d_tables, sizeof(Tables)));
+    HIP_CHECK(hipMalloc(&e->d_ref, sizeof(MemberRef)));
     HIP_CHECK(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice));
     HIP_CHECK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
@@ -1784,6 +1831,7 @@ int reina_destroy(reina_engine_t *e) {
     }
     hipFree(e->d_params);
     hipFree(e->d_tables);
+    hipFree(e->d_ref);
     delete e;
     return REINA_OK;
 }
@@ -1798,13 +1846,19 @@ int reina_bind_buffers(reina_engine_t *e, const reina_buffers_t *b) {
         }
     e->buf = *b;
     e->bound = true;
+    MemberRef r;
+    r.P = e->d_params;
+    r.T = e->d_tables;
+    r.B = e->buf;
+    r.history_base = nullptr;
+    HIP_CHECK(hipMemcpy(e->d_ref, &r, sizeof(MemberRef), hipMemcpyHostToDevice));
     return REINA_OK;
 }
 
 int reina_init_state(reina_engine_t *e, int32_t beds, int32_t icu, void *stream) {
     if (!e || !e->bound) return REINA_E_NOT_BOUND;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_init, dim3(grid_for(e->cfg.n_agents, 256, 4096)), dim3(256), 0, s, e->d_params, e->buf, beds, icu);
+    hipLaunchKernelGGL(k_init, dim3(grid_for(e->cfg.n_agents, 256, 4096), 1), dim3(256), 0, s, e->d_ref, beds, icu);
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
@@ -1833,13 +1887,13 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     return REINA_OK;
 }
 
-int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream) {
-    if (!e || !day) return REINA_E_INVALID;
-    if (!e->bound) return REINA_E_NOT_BOUND;
-    hipStream_t s = (hipStream_t)stream;
-    const reina_day_t dp = *day;
+// One day's launches for K engine instances at once (K = 1: a single engine; K > 1: a group of
+// identically configured engines, one launch per phase for all of them, member = blockIdx.y).
+// `e` is the representative engine: geometry, scenario flags, optional second stream.
+static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp,
+                            uint32_t hist_slot, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
-    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp, e->overlap ? 0 : 1);
+    hipLaunchKernelGGL(k_prologue, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, e->overlap ? 0 : 1, hist_slot);
     if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
     uint32_t n_pre = 0, n_post = 0;
     for (uint32_t b = 0; b < dp.n_import_batches; b++)
@@ -1847,44 +1901,44 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
     hipStream_t s2 = e->overlap ? e->s2 : s;
     if (e->testing_ever) {
         // test queue + tracing touch only infected / removed agents and the detection counters;
-        // weekly imports touch only never-infected agents: run them side by side
+        // weekly imports touch only never-infected agents: they may run side by side
         if (e->overlap) {
             HIP_CHECK(hipEventRecord(e->ev_fork1, s));
             HIP_CHECK(hipStreamWaitEvent(s2, e->ev_fork1, 0));
         }
         const int g = grid_for(N / 64 + 1, 256, 256);
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            hipLaunchKernelGGL(k_test_trace<0>, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);  // detects + traces
-            hipLaunchKernelGGL(k_test_trace<1>, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
+            hipLaunchKernelGGL(k_test_trace<0>, dim3(g, K), dim3(256), 0, s2, refs, dp);  // detects + traces
+            hipLaunchKernelGGL(k_test_trace<1>, dim3(g, K), dim3(256), 0, s2, refs, dp);
         } else {
-            hipLaunchKernelGGL(k_test_detect, dim3(g), dim3(256), 0, s2, e->d_params, e->buf, dp);
+            hipLaunchKernelGGL(k_test_detect, dim3(g, K), dim3(256), 0, s2, refs, dp);
         }
         if (e->overlap) HIP_CHECK(hipEventRecord(e->ev_join1, s2));
     }
-    if (n_post && e->overlap) hipLaunchKernelGGL(k_imports_post, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp, n_pre);
+    if (n_post && e->overlap) hipLaunchKernelGGL(k_imports_post, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, n_pre);
     if (e->testing_ever && e->overlap) HIP_CHECK(hipStreamWaitEvent(s, e->ev_join1, 0));
-    if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1), dim3(PRO_THREADS), 0, s, e->d_params, e->buf, dp);
+    if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
     // scan geometry: tiles of 512 agents, as many waves as tiles (small populations) up to 8192
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
     uint32_t scan_blocks = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;  // one 512-agent tile per wave until the grid cap
     if (scan_blocks < 1) scan_blocks = 1;
     if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
     const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
-    if (e->profile) {
+    if (e->profile && K == 1) {
         // start/stop timestamps ride on the kernel's own dispatch packet: no extra stream commands
         const size_t ev_s0 = take_event(e), ev_s1 = take_event(e);
-        hipExtLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SCAN_THREADS), 0, s, e->ev_pool[ev_s0], e->ev_pool[ev_s1], 0,
-                              e->d_params, e->buf, dp);
+        hipExtLaunchKernelGGL(k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, e->ev_pool[ev_s0], e->ev_pool[ev_s1], 0,
+                              refs, dp);
         e->scan_pairs.emplace_back(ev_s0, ev_s1);
     } else {
-        hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SCAN_THREADS), 0, s, e->d_params, e->buf, dp);
+        hipLaunchKernelGGL(k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, refs, dp);
     }
-    // bed / ICU events (one workgroup, latency-bound) run beside the contact kernel (whole chip)
+    // bed / ICU events (one workgroup per member, latency-bound) may run beside the contact kernel
     if (e->overlap) {
         HIP_CHECK(hipEventRecord(e->ev_fork2, s));
         HIP_CHECK(hipStreamWaitEvent(s2, e->ev_fork2, 0));
     }
-    hipLaunchKernelGGL(k_hospital, dim3(1), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s2, e->d_params, e->buf, dp, scan_waves, scan_tiles);
+    hipLaunchKernelGGL(k_hospital, dim3(1, K), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s2, refs, dp, scan_waves, scan_tiles);
     if (e->overlap) {
         HIP_CHECK(hipEventRecord(e->ev_join2, s2));
         e->join2_pending = true;
@@ -1892,36 +1946,43 @@ int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream
     {
         uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
         if (con_blocks > 512) con_blocks = 512;
-        hipLaunchKernelGGL(k_contacts, dim3(con_blocks), dim3(CON_THREADS), con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards), s,
-                           e->d_params, e->d_tables, e->buf, dp, scan_waves, scan_tiles, e->uniform_meta);
+        hipLaunchKernelGGL(k_contacts, dim3(con_blocks, K), dim3(CON_THREADS), con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards), s,
+                           refs, dp, scan_waves, scan_tiles, e->uniform_meta);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
 
-int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) {
-    if (!e || !day) return REINA_E_INVALID;
-    if (!e->bound) return REINA_E_NOT_BOUND;
-    hipStream_t s = (hipStream_t)stream;
-    const reina_day_t dp = *day;
+static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
     if (e->join2_pending) {  // installs read list flags the hospital kernel may clear: join first
         HIP_CHECK(hipStreamWaitEvent(s, e->ev_join2, 0));
         e->join2_pending = false;
     }
     if (e->cfg.n_shards > 1)
-        hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256)), dim3(256), 0, s, e->d_params, e->buf, dp);
+        hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-        uint32_t scan_blocks = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;  // one 512-agent tile per wave until the grid cap
+        uint32_t scan_blocks = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;
         if (scan_blocks < 1) scan_blocks = 1;
         if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
         int ig = grid_for(N / 64 + 1, 256, 512) * 2;  // even: candidates / deferred lists
-        hipLaunchKernelGGL(k_install, dim3(ig), dim3(256), 0, s, e->d_params, e->buf, dp,
-                           scan_blocks * SCAN_WAVES, scan_tiles);
+        hipLaunchKernelGGL(k_install, dim3(ig, K), dim3(256), 0, s, refs, dp, scan_blocks * SCAN_WAVES, scan_tiles);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
+}
+
+int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream) {
+    if (!e || !day) return REINA_E_INVALID;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    return launch_day_begin(e, e->d_ref, 1, *day, 0, (hipStream_t)stream);
+}
+
+int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) {
+    if (!e || !day) return REINA_E_INVALID;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    return launch_day_end(e, e->d_ref, 1, *day, (hipStream_t)stream);
 }
 
 int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
@@ -1945,6 +2006,78 @@ int reina_run_days_hist(reina_engine_t *e, const reina_day_t *days, uint32_t n_d
         int rc = reina_step_day(e, &d, stream);
         if (rc) return rc;
     }
+    return REINA_OK;
+}
+
+struct reina_group {
+    std::vector<reina_engine_t *> members;
+    MemberRef *d_refs = nullptr;
+    std::vector<MemberRef> h_refs;
+};
+
+int reina_group_create(reina_engine_t **engines, uint32_t n, reina_group_t **out) {
+    if (!engines || !out || n == 0 || n > 65535) return REINA_E_INVALID;
+    for (uint32_t k = 0; k < n; k++) {
+        reina_engine_t *m = engines[k];
+        if (!m || !m->bound) return REINA_E_NOT_BOUND;
+        if (m->cfg.n_agents != engines[0]->cfg.n_agents || m->cfg.nr_ages != engines[0]->cfg.nr_ages ||
+            m->cfg.nr_variants != engines[0]->cfg.nr_variants || m->cfg.n_shards != 1 ||
+            std::memcmp(m->cfg.age_start, engines[0]->cfg.age_start, sizeof(m->cfg.age_start)) != 0) {
+            g_last_error = "group members must be unsharded engines of the same population";
+            return REINA_E_INVALID;
+        }
+    }
+    reina_group *g = new reina_group();
+    g->members.assign(engines, engines + n);
+    g->h_refs.resize(n);
+    for (uint32_t k = 0; k < n; k++) {
+        g->h_refs[k].P = engines[k]->d_params;
+        g->h_refs[k].T = engines[k]->d_tables;
+        g->h_refs[k].B = engines[k]->buf;
+        g->h_refs[k].history_base = nullptr;
+    }
+    HIP_CHECK(hipMalloc(&g->d_refs, sizeof(MemberRef) * n));
+    *out = g;
+    return REINA_OK;
+}
+
+int reina_group_destroy(reina_group_t *g) {
+    if (!g) return REINA_E_INVALID;
+    hipFree(g->d_refs);
+    delete g;
+    return REINA_OK;
+}
+
+int reina_group_upload_contact_tables(reina_group_t *g, const reina_contact_tables_t *t, void *stream) {
+    if (!g) return REINA_E_INVALID;
+    for (auto m : g->members) {
+        int rc = reina_upload_contact_tables(m, t, stream);
+        if (rc) return rc;
+    }
+    return REINA_OK;
+}
+
+int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_days, int32_t *const *history_bases,
+                         void *stream) {
+    if (!g || !days) return REINA_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t K = (uint32_t)g->members.size();
+    for (uint32_t k = 0; k < K; k++) g->h_refs[k].history_base = history_bases ? history_bases[k] : nullptr;
+    HIP_CHECK(hipMemcpyAsync(g->d_refs, g->h_refs.data(), sizeof(MemberRef) * K, hipMemcpyHostToDevice, s));
+    reina_engine_t *e0 = g->members[0];
+    bool tested = false;  // the test-queue kernels run for all members once any member ever tested
+    for (auto m : g->members) tested = tested || m->testing_ever;
+    for (uint32_t d = 0; d < n_days; d++) tested = tested || days[d].testing_mode != RT_NO_TESTING;
+    e0->testing_ever = e0->testing_ever || (tested && n_days == 0);
+    for (uint32_t d = 0; d < n_days; d++) {
+        reina_day_t dp = days[d];
+        dp.history_row = nullptr;
+        int rc = launch_day_begin(e0, g->d_refs, K, dp, d, s);
+        if (rc) return rc;
+        rc = launch_day_end(e0, g->d_refs, K, dp, s);
+        if (rc) return rc;
+    }
+    for (auto m : g->members) m->testing_ever = m->testing_ever || e0->testing_ever;
     return REINA_OK;
 }
 

@@ -45,6 +45,7 @@ L_NR = 32
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'upload_contact_tables',
                  'step_day', 'step_day_begin', 'step_day_end', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
+                 'group_create', 'group_destroy', 'group_upload_contact_tables', 'group_run_days',
                  'last_error', 'abi_version')
 
 
@@ -132,6 +133,10 @@ def bind_abi(lib, prefix):
     f['run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp]
     f['run_days_hist'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp, vp]
     f['read_counters'].argtypes = [vp, vp, vp]
+    f['group_create'].argtypes = [ctypes.POINTER(vp), ctypes.c_uint32, ctypes.POINTER(vp)]
+    f['group_destroy'].argtypes = [vp]
+    f['group_upload_contact_tables'].argtypes = [vp, ctypes.POINTER(ContactTablesABI), vp]
+    f['group_run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, ctypes.POINTER(vp), vp]
     f['sample'].argtypes = [ctypes.POINTER(Disease), ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                             ctypes.c_float, ctypes.c_int, vp]
     f['profile_enable'].argtypes = [vp, ctypes.c_int]
@@ -243,7 +248,8 @@ class Engine:
     def init_state(self, beds, icu_units):
         self._check(self.f['init_state'](self._h, int(beds), int(icu_units), self.alloc.stream()), 'init_state')
 
-    def upload_contact_tables(self, nrc, count, threshold, meta, mask_p, ranges):
+    @staticmethod
+    def _tables_abi(nrc, count, threshold, meta, mask_p, ranges):
         arrs = [np.ascontiguousarray(nrc, dtype=np.float32), np.ascontiguousarray(count, dtype=np.int32),
                 np.ascontiguousarray(threshold, dtype=np.uint32), np.ascontiguousarray(meta, dtype=np.uint32),
                 np.ascontiguousarray(mask_p, dtype=np.float32)]
@@ -252,6 +258,10 @@ class Engine:
         for k, (lo, hi) in enumerate(ranges):
             t.range_min[k] = int(lo)
             t.range_max[k] = int(hi)
+        return t, arrs
+
+    def upload_contact_tables(self, nrc, count, threshold, meta, mask_p, ranges):
+        t, _keep = self._tables_abi(nrc, count, threshold, meta, mask_p, ranges)
         self._check(self.f['upload_contact_tables'](self._h, ctypes.byref(t), self.alloc.stream()), 'upload_contact_tables')
 
     def step_day(self, day):
@@ -289,6 +299,43 @@ class Engine:
         a, b, c = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_double()
         self._check(self.f['profile_read'](self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), 'profile_read')
         return dict(scan_ms_total=a.value, scan_launches=b.value, all_ms_total=c.value)
+
+
+class EngineGroup:
+    """K unsharded engines of the same population (different seeds) stepped with one launch per
+    phase for all of them (include/reina_hip.h: reina_group_*).  Members stay usable on their own."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        e0 = self.engines[0]
+        self.f = e0.f
+        self.alloc = e0.alloc
+        hs = (ctypes.c_void_p * len(self.engines))(*[e._h.value for e in self.engines])
+        self._h = ctypes.c_void_p()
+        e0._check(self.f['group_create'](hs, len(self.engines), ctypes.byref(self._h)), 'group_create')
+
+    def close(self):
+        if self._h:
+            self.f['group_destroy'](self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_contact_tables(self, nrc, count, threshold, meta, mask_p, ranges):
+        t, _keep = Engine._tables_abi(nrc, count, threshold, meta, mask_p, ranges)
+        self.engines[0]._check(self.f['group_upload_contact_tables'](self._h, ctypes.byref(t), self.alloc.stream()),
+                               'group_upload_contact_tables')
+
+    def run_day_array(self, arr, n, history_ptrs):
+        """history_ptrs: one device pointer per member (row k of member m at ptr[m] + k rows) or None."""
+        hp = None
+        if history_ptrs is not None:
+            hp = (ctypes.c_void_p * len(self.engines))(*[int(p) for p in history_ptrs])
+        self.engines[0]._check(self.f['group_run_days'](self._h, arr, n, hp, self.alloc.stream()), 'group_run_days')
 
 
 _hip_lib = None

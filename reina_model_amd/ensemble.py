@@ -3,10 +3,17 @@
 Counterpart of the reference's `run_monte_carlo` (calc/simulation.py:349-385: a
 `multiprocessing.Pool(8)` over seeds).  A single HUS-sized simulation keeps only a few per cent of
 an MI355X busy (its day is a chain of short, latency-bound kernels), so an ensemble is run as K
-engine instances side by side: every member owns its HBM state and its own HIP stream, and a
-small pool of host threads issues the members' days (the C ABI call releases the GIL), letting the
-GPU overlap the members' kernels.  Members are fully independent (BASELINE config 5: "replicas
-only", no collective); over several GPUs the seeds are simply partitioned across ranks.
+engine instances side by side, every member owning its HBM state.  Two ways to issue the work:
+
+  * batched (default): the members form an engine group (include/reina_hip.h: reina_group_*) and
+    every phase of a day is ONE kernel launch covering all members (member = blockIdx.y) -- the
+    launch count per day does not grow with K, so the host never becomes the limit;
+  * threaded: every member has its own HIP stream and a small pool of host threads issues the
+    members' days (the C ABI call releases the GIL); kept for members of differing scenarios.
+
+Members are fully independent (BASELINE config 5: "replicas only", no collective); over several
+GPUs the seeds are simply partitioned across ranks.  Results are bit-identical either way and
+identical to running each seed alone (tests/test_parity_gpu.py).
 """
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -16,14 +23,56 @@ import numpy as np
 from . import simulation
 
 
+def run_group_plan(contexts, plan, record_history=True):
+    """Execute `plan` (Context.make_plan) for all `contexts` as one engine group.  Returns
+    history[len(contexts), days, COUNTER_WORDS] (host) or None."""
+    from . import engine as _eng
+    group = _eng.EngineGroup([c.engine for c in contexts])
+    a = group.alloc
+    days = plan['days']
+    K = len(contexts)
+    hist = a.zeros(K * days * _eng.COUNTER_WORDS, np.int32) if record_history else None
+    row = 4 * _eng.COUNTER_WORDS
+    done = 0
+    for tables, arr, n in plan['segments']:
+        if tables is not None:
+            group.upload_contact_tables(*tables)
+        ptrs = [a.ptr(hist) + row * (m * days + done) for m in range(K)] if record_history else None
+        group.run_day_array(arr, n, ptrs)
+        done += n
+    for c in contexts:
+        c.mobility_history = plan['mobility_history']
+        c.day = plan['start_day'] + days
+    out = None
+    if record_history:
+        out = a.to_host(hist).reshape(K, days, _eng.COUNTER_WORDS)
+    for c in contexts:
+        c._raise_on_problem(c.engine.read_counters())
+    group.close()
+    return out
+
+
 def run_ensemble(variables, seeds, days, age_counts=None, device='cuda:0', threads=8, concurrent=None,
-                 interventions=None):
+                 interventions=None, batched=True):
     """Run one simulation per seed for `days` days. Returns history[len(seeds), days, COUNTER_WORDS]
     (row d = counters before day d, as Context.run). `concurrent` bounds how many members hold HBM
     state at once (default: all)."""
     import torch
     seeds = list(seeds)
     concurrent = len(seeds) if concurrent is None else max(1, int(concurrent))
+    if batched:
+        planner = simulation.make_context(variables, age_counts=age_counts, seed=seeds[0], device=device,
+                                          interventions=interventions)
+        plan = planner.make_plan(days)
+        del planner
+        outs = []
+        for start in range(0, len(seeds), concurrent):
+            ctxs = [simulation.make_context(variables, age_counts=age_counts, seed=sd, device=device,
+                                            interventions=interventions)
+                    for sd in seeds[start:start + concurrent]]
+            outs.append(run_group_plan(ctxs, plan))
+            del ctxs
+        return np.concatenate(outs)
     out = [None] * len(seeds)
     dev = torch.device(device)
     lock = threading.Lock()

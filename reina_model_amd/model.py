@@ -462,6 +462,7 @@ class Context:
         on the random seed, so one plan can drive every member of a Monte-Carlo ensemble
         (reina_model_amd/ensemble.py).  Advances this Context's host-side state by `days`."""
         segments = []   # (packed tables or None, ctypes Day array, n)
+        start_day = self.day
         pending = []
         tables = None
         mobility = []
@@ -477,11 +478,13 @@ class Context:
             self.day += 1
         if pending:
             segments.append((tables, (_eng.Day * len(pending))(*pending), len(pending)))
-        return dict(segments=segments, days=days, mobility_history=mobility)
+        return dict(segments=segments, days=days, mobility_history=mobility, start_day=start_day)
 
     def run_plan(self, plan, record_history=True):
         """Execute a plan made by make_plan (of this Context or of another one with the same
-        scenario).  Returns history[days, COUNTER_WORDS] like run()."""
+        scenario).  Returns history[days, COUNTER_WORDS] like run().  The scenario's host-side state
+        (intervention cursor, contact matrix) advances only in the Context that MADE the plan:
+        continue a replayed simulation with further plans of that same planner."""
         days = plan['days']
         a = self.engine.alloc
         hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None
@@ -494,6 +497,7 @@ class Context:
             self.engine.run_day_array(arr, n, ptr)
             done += n
         self.mobility_history = plan['mobility_history']
+        self.day = plan['start_day'] + days
         if record_history:
             out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
             self._raise_on_problem(self.engine.read_counters())

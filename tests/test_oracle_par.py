@@ -96,3 +96,23 @@ def test_import_only_day_places_every_import_once():
     assert ((hot & 7) == 1).sum() == 500
     age_of = np.repeat(np.arange(ctx.nr_ages), ctx.age_counts)
     assert age_of[(hot & 7) == 1].max() < 70  # imported_infection_ages weights end at 69
+
+
+def test_group_api_on_oracle_b():
+    """The group entry points (reina_group_* / par_group_*) through the product's host code
+    (ensemble.run_group_plan), CPU engine: identical to stepping each member alone."""
+    import copy
+    import numpy as np
+    import par_backend
+    from reina_model_amd import datasets, ensemble, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=8, icu_units=2)
+    ages = datasets.scaled_population(6000)
+    mk = lambda s: simulation.make_context(v, age_counts=ages, seed=s, engine_factory=par_backend.par_engine_factory)
+    plan = mk(0).make_plan(90)
+    members = [mk(s) for s in (1, 2, 3)]
+    hist = ensemble.run_group_plan(members, plan)
+    for m, s in enumerate((1, 2, 3)):
+        assert np.array_equal(hist[m], mk(s).run(90))
+    assert members[0].day == 90

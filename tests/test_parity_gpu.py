@@ -251,3 +251,45 @@ def test_random_scenarios(case):
     rng = np.random.default_rng(1000 + case)
     v, ages, days, ivs = _random_scenario(rng)
     _run_and_compare(v, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40)
+
+
+def test_engine_group_equals_individual_members():
+    """Monte-Carlo group (one launch per phase for all members, member = blockIdx.y): every
+    member's per-day counters and final state == oracle B run alone with that member's seed;
+    kitchen-sink scenario so every kernel (tracing, vaccination, imports, new beds) is covered."""
+    import par_backend
+    from reina_model_amd import ensemble
+    _, meta = load_run('mini_kitchen_s0')
+    v, ages, ivs = variables_for(meta), np.asarray(meta['age_counts']), meta['interventions']
+    seeds = [3, 11, 12, 500, 77]
+    days = meta['days']
+    planner = simulation.make_context(v, age_counts=ages, seed=0, interventions=ivs)
+    plan = planner.make_plan(days)
+    members = [simulation.make_context(v, age_counts=ages, seed=s, interventions=ivs) for s in seeds]
+    hist = ensemble.run_group_plan(members, plan)
+    assert hist.shape == (len(seeds), days, eng.COUNTER_WORDS)
+    for m, s in enumerate(seeds):
+        cpu = simulation.make_context(v, age_counts=ages, seed=s, interventions=ivs,
+                                      engine_factory=par_backend.par_engine_factory)
+        hc = cpu.run(days)
+        assert np.array_equal(hist[m], hc), 'member %d (seed %d)' % (m, s)
+        assert np.array_equal(members[m].engine.read_counters(), cpu.engine.read_counters())
+        _assert_state_equal(members[m], cpu)
+    # members stay usable on their own after the group is gone (the planner keeps the scenario's
+    # host-side state, so the continuation plan comes from it)
+    more = planner.make_plan(5)
+    h1 = members[0].run_plan(more)
+    cpu0 = simulation.make_context(v, age_counts=ages, seed=seeds[0], interventions=ivs,
+                                   engine_factory=par_backend.par_engine_factory)
+    cpu0.run(days)
+    assert np.array_equal(h1, cpu0.run(5))
+
+
+def test_run_ensemble_batched_equals_threaded():
+    from reina_model_amd import ensemble
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=12, icu_units=2)
+    ages = datasets.scaled_population(30000)
+    a = ensemble.run_ensemble(v, range(6), 120, age_counts=ages, batched=True, concurrent=4)
+    b = ensemble.run_ensemble(v, range(6), 120, age_counts=ages, batched=False)
+    assert np.array_equal(a, b)
