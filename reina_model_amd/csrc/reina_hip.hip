@@ -246,7 +246,7 @@ __device__ void flush_new_infections(const reina_buffers_t &B, int32_t *new_by_a
 __global__ void k_init(const MemberRef *M_, int32_t beds, int32_t icu) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     uint32_t N = P->n_agents;
     uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
@@ -445,8 +445,10 @@ __device__ void pro_vaccinate(const DevParams *P, const reina_buffers_t &B, cons
 __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const MemberRef *M_, reina_day_t dp, int do_post, uint32_t hist_slot) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
-    if (mref_.history_base) dp.history_row = mref_.history_base + (size_t)hist_slot * REINA_COUNTER_WORDS;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
+    // (dp itself stays untouched: writing a field of the by-value kernel argument would spill the whole struct)
+    int32_t *const history_row =
+        mref_.history_base ? mref_.history_base + (size_t)hist_slot * REINA_COUNTER_WORDS : dp.history_row;
     __shared__ uint8_t placed[PRO_MAX_IMPORTS];
     __shared__ uint32_t s_wave_cnt[PRO_THREADS / 64];
     __shared__ uint32_t s_unplaced;
@@ -460,8 +462,8 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const MemberRef *M_, r
     if (tid < REINA_MAX_AGES) new_by_age[tid] = 0;
     if (tid < REINA_MAX_VARIANTS) new_by_variant[tid] = 0;
     // generate_state() is taken BEFORE iterate() (calc/simulation.py:195 vs :270)
-    if (dp.history_row)
-        for (int k = tid; k < REINA_COUNTER_WORDS; k += PRO_THREADS) dp.history_row[k] = B.counters[k];
+    if (history_row)
+        for (int k = tid; k < REINA_COUNTER_WORDS; k += PRO_THREADS) history_row[k] = B.counters[k];
     __syncthreads();
     if (tid == 0) {
         s_import_base = 0;
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(PRO_THREADS) void k_imports_post(const MemberRef *M
                                                               uint32_t import_base) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     __shared__ uint8_t placed[PRO_MAX_IMPORTS];
     __shared__ uint32_t s_unplaced;
     __shared__ uint32_t s_import_base;
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(PRO_THREADS) void k_imports_post(const MemberRef *M
 __global__ __launch_bounds__(PRO_THREADS) void k_vaccinate(const MemberRef *M_, reina_day_t dp) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     __shared__ uint32_t s_wave_cnt[PRO_THREADS / 64];
     __shared__ int32_t s_scalar;
     pro_vaccinate(P, B, dp, s_wave_cnt, &s_scalar);
@@ -552,7 +554,7 @@ __device__ __forceinline__ void queue_append(const DevParams *P, const reina_buf
 __global__ __launch_bounds__(256) void k_test_detect(const MemberRef *M_, reina_day_t dp) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     __shared__ int32_t s_det[REINA_MAX_AGES];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     if (B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] <= (int)(blockIdx.x * blockDim.x)) return;
@@ -596,7 +598,7 @@ template <int LEVEL>
 __global__ __launch_bounds__(256) void k_test_trace(const MemberRef *M_, reina_day_t dp) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     __shared__ int32_t s_det[REINA_MAX_AGES];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     const int cur = dp.day & 1, nxt = cur ^ 1;
@@ -790,7 +792,7 @@ __device__ __forceinline__ uint32_t scan_word(const DevParams *P, ScanLists &L, 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const MemberRef *M_, reina_day_t dp) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t N = P->n_agents;
     const uint32_t n4 = N >> 2;
@@ -936,7 +938,7 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const MemberRef *M_, 
                                                            uint32_t scan_waves, uint32_t scan_tiles) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *ev = reinterpret_cast<uint64_t *>(smem);               // [M2]
     __shared__ int s_b, s_c;
@@ -1248,7 +1250,7 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const MemberRef *M_, r
                                                           uint32_t scan_waves, uint32_t scan_tiles, int uniform_meta) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     const Tables *T = mref_.T;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     ConShared &S = *reinterpret_cast<ConShared *>(smem_raw);
@@ -1453,7 +1455,7 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const MemberRef *M_, r
 __global__ __launch_bounds__(256) void k_remote(const MemberRef *M_, reina_day_t dp) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     __shared__ uint32_t s_pre[REINA_MAX_RANGES * REINA_MAX_VARIANTS + 1];  // exclusive prefix of cell counts
     const int tid = threadIdx.x;
@@ -1529,7 +1531,7 @@ __global__ __launch_bounds__(256) void k_install(const MemberRef *M_, reina_day_
                                                  uint32_t scan_waves, uint32_t scan_tiles) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
-    const reina_buffers_t &B = mref_.B;
+    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     __shared__ int32_t new_by_age[REINA_MAX_AGES];
     __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
