@@ -16,7 +16,7 @@ on the 11 days the mobility factors change), exactly what the reference's iterat
 Extra objects on the line:
   roofline     dominant kernel k_scan: algorithmic bytes per launch (4 B hot word read per agent +
                4 B written back per infected agent) / mean launch duration
-               from HIP events recorded on the launch stream inside the timed region, vs 8 TB/s.
+               from HIP events recorded on the launch stream inside the timed region (every --time-every-th day), vs 8 TB/s.
   cpu_baseline the sequential C oracle (oracle/reina_seq.c, bit-exact vs the reference cythonsim)
                timed on one host core on a bounded sample (first days of the same workload).
   large        the same measurement on BASELINE configs[2] (synthetic 50 M agents, HUS age shape,
@@ -55,7 +55,7 @@ def scaled_scenario(variables, total_agents):
     return v, datasets.scaled_population(total_agents)
 
 
-def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0):
+def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=1):
     import numpy as np
     import torch
     from reina_model_amd import engine as eng
@@ -66,7 +66,7 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0):
         # idle power state and pays one-time runtime costs (first timestamped dispatches, staging
         # buffers of the table uploads, allocator pools) before the measured simulation exists
         pre = simulation.make_context(variables, age_counts=ages, seed=seed + 1000003, device=device, comm=comm)
-        pre.engine.profile_enable(True)
+        pre.engine.profile_enable(stride)
         pre.run(preheat, record_history=True)
         pre.synchronize()
         pre.engine.profile_read()
@@ -74,7 +74,7 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0):
     ctx = simulation.make_context(variables, age_counts=ages, seed=seed, device=device, comm=comm)
     # the event-timed launch path is switched on BEFORE the warm-up so its one-time costs (event
     # pool, first timestamped dispatches) are not billed to the timed region
-    ctx.engine.profile_enable(True)
+    ctx.engine.profile_enable(stride)
     if warmup:
         ctx.run(warmup, record_history=False)
     ctx.synchronize()
@@ -95,18 +95,21 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0):
     A = eng.MAX_AGES
     inf = hist[:, eng.C_NAMES.index('infected') * A:(eng.C_NAMES.index('infected') + 1) * A].sum(axis=1)
     sc = hist[:, eng.C_NR * A:]
+    timed = (np.arange(steps) + warmup) % stride == 0   # the days whose scan launch carried timestamps
     stats = dict(
-        mean_infected=float(inf.mean()),
+        mean_infected=float(inf[timed].mean() if timed.any() else inf.mean()),
+        mean_infected_all_days=float(inf.mean()),
         contacts=float(sc[:, eng.S_EXPOSED_PER_DAY].sum()),
         new_infections=float(hist[:, eng.C_NAMES.index('new_infections') * A:(eng.C_NAMES.index('new_infections') + 1) * A].sum()),
         final_all_infected=int(hist[-1, eng.C_NAMES.index('all_infected') * A:(eng.C_NAMES.index('all_infected') + 1) * A].sum()),
     )
     if comm is not None:
         stats['mean_infected'] /= comm.world  # per-shard share for the per-launch byte count
+        stats['mean_infected_all_days'] /= comm.world
     return t1 - t0, prof, stats, ctx.total_people
 
 
-def roofline_obj(n_agents, steps, prof, stats):
+def roofline_obj(n_agents, steps, prof, stats, stride=1):
     # algorithmic bytes of one k_scan launch: every agent's 4-byte hot word read once, the hot
     # word of every infected agent written back (the 4*N + 4*N_inf terms)
     bytes_per_launch = 4.0 * n_agents + 4.0 * stats['mean_infected']
@@ -116,7 +119,8 @@ def roofline_obj(n_agents, steps, prof, stats):
     return dict(bound='hbm', kernel='k_scan', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
                 bytes_per_launch=bytes_per_launch, avg_launch_ms=round(ms, 6), launches=launches,
-                day_algorithmic_bytes=round((4.0 * n_agents * steps + 4.0 * stats['mean_infected'] * steps
+                launches_note='timestamped launches: every %d-th day of the timed region' % stride,
+                day_algorithmic_bytes=round((4.0 * n_agents * steps + 4.0 * stats['mean_infected_all_days'] * steps
                                              + 4.0 * stats['contacts'] + 12.0 * stats['new_infections']) / steps, 1))
 
 
@@ -145,6 +149,8 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-large', action='store_true')
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--time-every', type=int, default=8,
+                    help='k_scan launches carry HIP event timestamps on every k-th day of the timed region')
     ap.add_argument('--preheat-days', type=int, default=200,
                     help='days of a throw-away simulation run before the measured one (GPU clocks, one-time costs)')
     a = ap.parse_args()
@@ -174,7 +180,7 @@ def main():
         ages = datasets.get_population_for_area()
         workload = 'HUS 1685983 agents, default scenario (variables.py:227-435), %d days' % a.steps
 
-    dt, prof, stats, n_local = run_gpu(v, ages, a.seed, a.steps, a.warmup, device, dist, preheat=a.preheat_days)
+    dt, prof, stats, n_local = run_gpu(v, ages, a.seed, a.steps, a.warmup, device, dist, preheat=a.preheat_days, stride=a.time_every)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,7 +200,7 @@ def main():
             'config': {'workload': workload, 'agents_total': total_agents,
                        'parallelism': 'single GPU' if world == 1 else 'agents sharded x%d, one 8 KB RCCL all-reduce of infection pressure per day' % world,
                        'final_all_infected': stats['final_all_infected']},
-            'roofline': roofline_obj(n_agents, a.steps, prof, stats),
+            'roofline': roofline_obj(n_agents, a.steps, prof, stats, a.time_every),
         }
         traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(traffic_file):
@@ -207,12 +213,12 @@ def main():
                 pass
         if not a.no_large and world == 1 and not a.agents:
             vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.large_agents)
-            dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, preheat=min(a.preheat_days, 60))
+            dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, preheat=min(a.preheat_days, 60), stride=a.time_every)
             out['large'] = {
                 'workload': 'synthetic %d agents (BASELINE configs[2]), default scenario scaled, %d days' % (nl, a.steps),
                 'value': round(nl * a.steps / dtl, 1), 'unit': 'agent-days/s',
                 'ms_per_step': round(dtl * 1000 / a.steps, 6),
-                'roofline': roofline_obj(nl, a.steps, profl, statsl),
+                'roofline': roofline_obj(nl, a.steps, profl, statsl, a.time_every),
                 'final_all_infected': statsl['final_all_infected'],
             }
         if not a.no_cpu:

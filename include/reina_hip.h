@@ -256,7 +256,9 @@ int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_d
 /* replaces Context.generate_state's reads (main.pyx:1813-1857): copies the counter block to host
  * (synchronises `stream`) */
 int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);
-/* timing hooks for bench.py: HIP events recorded around the scan kernel on `stream` */
+/* timing hooks for bench.py: HIP events recorded around the scan kernel on `stream`.
+ * enable: 0 off, 1 every day, k > 1 the days with day % k == 0 (a timestamped dispatch costs a
+ * few microseconds of stream time, which matters when a whole day takes 80) */
 int reina_profile_enable(reina_engine_t *e, int enable);
 int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_launches,
                        double *all_ms_total);

@@ -93,6 +93,7 @@ struct reina_engine {
     bool overlap = false;
     // profiling
     bool profile = false;
+    uint32_t profile_stride = 1;  // time the scan launch of every profile_stride-th day
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<size_t, size_t>> scan_pairs, day_pairs;
@@ -1926,7 +1927,7 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     if (scan_blocks < 1) scan_blocks = 1;
     if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
     const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
-    if (e->profile && K == 1) {
+    if (e->profile && K == 1 && dp.day % e->profile_stride == 0) {
         // start/stop timestamps ride on the kernel's own dispatch packet: no extra stream commands
         const size_t ev_s0 = take_event(e), ev_s1 = take_event(e);
         hipExtLaunchKernelGGL(k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, e->ev_pool[ev_s0], e->ev_pool[ev_s1], 0,
@@ -2095,6 +2096,7 @@ int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream) {
 int reina_profile_enable(reina_engine_t *e, int enable) {
     if (!e) return REINA_E_INVALID;
     e->profile = enable != 0;
+    e->profile_stride = enable > 1 ? (uint32_t)enable : 1u;
     // create the timing events up front: hipEventCreate inside the timed region costs microseconds each
     while (e->profile && e->ev_pool.size() < 2048) {
         hipEvent_t ev;

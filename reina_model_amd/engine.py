@@ -293,7 +293,8 @@ class Engine:
         return out
 
     def profile_enable(self, on=True):
-        self._check(self.f['profile_enable'](self._h, 1 if on else 0), 'profile_enable')
+        """on: False/0 off, True/1 every day, k > 1 every k-th day (day % k == 0)"""
+        self._check(self.f['profile_enable'](self._h, int(on)), 'profile_enable')
 
     def profile_read(self):
         a, b, c = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_double()

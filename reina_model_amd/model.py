@@ -607,6 +607,12 @@ class Context:
     def sample(self, what, age, severity=None, sample_size=10000):
         """10 000 draws of one per-agent quantity with the engine's samplers (host-side; each call
         advances a private stream like the reference advances its RandomPool)."""
+        if what == 'infectiousness':
+            # day -> infectiousness over days -100..99 (0 outside the 21-day profile, main.pyx:660-682)
+            days = list(range(-100, 100))
+            iot = dict(INFECTIOUSNESS_OVER_TIME)
+            vals = [float(np.float32(iot.get(d, 0.0))) for d in days]
+            return np.rec.fromarrays((days, vals), names=('day', 'val'))
         if what not in self.SAMPLE_KINDS:
             raise Exception('unknown sample type. supported: %s' % ', '.join(self.SAMPLE_KINDS))
         sev = -1 if severity is None else STR_TO_SEVERITY[severity]

@@ -9,6 +9,11 @@ Row d is the state BEFORE day d is simulated (the reference calls generate_state
 iterate(), :195 vs :270).  The day loop itself runs on the GPU without per-day host round trips
 (`Context.run`); `step_callback` is honoured every `callback_day_interval` days by running the
 simulation in stretches.
+
+Also here, with the reference's names: `sample_model_parameters` (:301-347), `simulate_monte_carlo`
+/ `run_monte_carlo` (:350-385; the reference maps 1000 seeds over a pool of 8 processes, here the
+seeds run as engine groups on the GPU, reina_model_amd/ensemble.py) and the `python -m` day table
+(:388-460): `python -m reina_model_amd.simulation [--days N] [--seed S] [--scenario ID]`.
 """
 import time
 from datetime import date, timedelta
@@ -123,3 +128,158 @@ def simulate_individuals(variables=None, step_callback=None, callback_day_interv
     adf = adf.unstack('attr').unstack('age_group')
     adf.columns = adf.columns.droplevel()
     return df, adf
+
+
+def _frames_from_history(ctx, hist, mobility_history, start_date, ms_per_day=0.0):
+    """(df, adf) of simulate_individuals from a recorded counter history[days, COUNTER_WORDS]."""
+    import pandas as pd
+    days = hist.shape[0]
+    age_groups = ctx.age_group_labels
+    date_index = pd.date_range(start_date, periods=days)
+    cols = POP_ATTRS + STATE_ATTRS + EXPOSURES_ATTRS + ['us_per_infected']
+    rows = []
+    ag_array = np.empty((days, len(POP_ATTRS), len(age_groups)), dtype='i')
+    for k in range(days):
+        s = ctx.state_from_counters(hist[k], mobility_factor=mobility_history[k])
+        for idx, attr in enumerate(POP_ATTRS):
+            ag_array[k, idx, :] = s[attr]
+        rec = {attr: s[attr].sum() for attr in POP_ATTRS}
+        for a in STATE_ATTRS:
+            rec[a] = s[a]
+        for place, nr in s['daily_contacts'].items():
+            rec['exposures_%s' % place] = nr
+        rec['us_per_infected'] = ms_per_day * 1000 / rec['infected'] if rec['infected'] else 0
+        rows.append(rec)
+    df = pd.DataFrame(rows, index=date_index, columns=cols)
+    adf = pd.DataFrame(
+        ag_array.flatten(),
+        index=pd.MultiIndex.from_product([date_index, POP_ATTRS, age_groups], names=['date', 'attr', 'age_group']),
+        columns=['pop'])
+    adf = adf.unstack('attr').unstack('age_group')
+    adf.columns = adf.columns.droplevel()
+    return df, adf
+
+
+def sample_model_parameters(what, age, severity=None, variables=None, device='cuda:0', engine_factory=None):
+    """calc/simulation.py:301-347: distribution of one per-agent quantity (`Context.sample`) in a
+    one-agent-per-age population.  Returns the value -> share Series (severity names for
+    'symptom_severity'; the day -> infectiousness Series for 'infectiousness').  The reference
+    also prints the table and opens a matplotlib window; that is left to the caller."""
+    import pandas as pd
+    if variables is None:
+        variables = copy_variables()
+    max_age = variables['max_age']
+    age_to_group = datasets.make_age_groups(max_age)
+    groups = list(np.unique(age_to_group))
+    pop_params = dict(
+        age_structure=np.ones(max_age + 1, dtype=np.int64),
+        contacts_per_day=datasets.get_contacts_per_day(variables['country']),
+        age_groups=dict(labels=groups, age_indices=[groups.index(x) for x in age_to_group]),
+        imported_infection_ages=variables['imported_infection_ages'],   # (the reference omits it and fails)
+    )
+    ctx = model.Context(pop_params, dict(hospital_beds=0, icu_units=0), create_disease_params(variables),
+                        '2020-01-01', device=device, engine_factory=engine_factory)
+    if variables.get('sample_limit_mobility', 0) != 0:
+        # the reference passes (type, value) to apply_intervention, which only accepts an
+        # intervention object (main.pyx:1880); the evident intent is a population-wide limit
+        ctx.apply_intervention(iv_tuple_to_obj(['limit-mobility', None, variables['sample_limit_mobility']],
+                                               tuple(v['name'] for v in variables['variants'])))
+        ctx.contact_matrix.init_day()
+    samples = ctx.sample(what, age, severity)
+    if what == 'infectiousness':
+        s = pd.Series(index=samples['day'], data=samples['val'])
+        return s[s != 0].sort_index()
+    s = pd.Series(samples)
+    c = s.value_counts().sort_index()
+    if what == 'symptom_severity':
+        c.index = c.index.map(model.SEVERITY_TO_STR)
+    return c / c.sum()
+
+
+def simulate_monte_carlo(seed, variables=None, device='cuda:0', engine_factory=None, age_counts=None):
+    """calc/simulation.py:350-359: one run with `random_seed = seed`; df gets a 'run' column."""
+    v = copy_variables() if variables is None else dict(variables)
+    v['random_seed'] = seed
+    df, _ = simulate_individuals(v, device=device, engine_factory=engine_factory, age_counts=age_counts)
+    df['run'] = seed
+    return df
+
+
+def run_monte_carlo(scenario_name, seeds=range(1000), device='cuda:0', group_size=64, days=None, write_csv=True,
+                    age_counts=None, engine_factory=None, variables=None):
+    """calc/simulation.py:362-385 with the seeds stepped as engine groups on one GPU instead of a
+    process pool: one DataFrame with every run's per-date rows, columns as simulate_individuals
+    plus 'run' and 'scenario'; written to reina_<scenario>.csv like the reference."""
+    import pandas as pd
+    from . import ensemble
+    from .scenarios import scenario_variables
+    v = scenario_variables(scenario_name, base=variables)
+    days = v['simulation_days'] if days is None else days
+    seeds = list(seeds)
+    dfs = []
+    for start in range(0, len(seeds), group_size):
+        part = seeds[start:start + group_size]
+        planner = make_context(v, age_counts=age_counts, seed=part[0], device=device, engine_factory=engine_factory)
+        plan = planner.make_plan(days)
+        members = [make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory)
+                   for sd in part]
+        t0 = time.perf_counter()
+        hist = ensemble.run_group_plan(members, plan)
+        ms_per_day = (time.perf_counter() - t0) * 1000 / days / len(part)
+        for m, sd in enumerate(part):
+            df, _ = _frames_from_history(members[m], hist[m], plan['mobility_history'],
+                                         date.fromisoformat(v['start_date']), ms_per_day)
+            df['run'] = sd
+            dfs.append(df)
+        del members, planner
+    df = pd.concat(dfs)
+    df.index.name = 'date'
+    df = df.reset_index()
+    df['scenario'] = scenario_name
+    if write_csv:
+        df.to_csv('reina_%s.csv' % scenario_name, index=False)
+    return df
+
+
+def main(argv=None):
+    """The day table the reference prints when run as a script (calc/simulation.py:411-447)."""
+    import argparse
+    from .scenarios import scenario_variables
+    ap = argparse.ArgumentParser(prog='python -m reina_model_amd.simulation')
+    ap.add_argument('--days', type=int, default=None)
+    ap.add_argument('--seed', type=int, default=None)
+    ap.add_argument('--scenario', default='default')
+    ap.add_argument('--device', default='cuda:0')
+    ap.add_argument('--interval', type=int, default=1, help='days between printed rows')
+    a = ap.parse_args(argv)
+    v = scenario_variables(a.scenario)
+    if a.days is not None:
+        v['simulation_days'] = a.days
+    if a.seed is not None:
+        v['random_seed'] = a.seed
+    state_attrs = ['ct_cases_per_day', 'r']
+    header = '%-10s' % 'day'
+    for attr in POP_ATTRS + state_attrs + ['exposures', 'us_per_infected']:
+        header += '%15s' % attr
+    print(header)
+
+    def step_callback(df):
+        for _, rec in df.dropna().iloc[-a.interval:].iterrows():
+            s = '%-12s' % rec.name.date().isoformat()
+            for attr in POP_ATTRS:
+                s += '%15d' % rec[attr]
+            s += '%15d' % rec['ct_cases_per_day']
+            s += '%13.2f' % rec['r']
+            s += '%15d' % sum(rec[x] for x in rec.index if 'exposures_' in x)
+            if rec['infected']:
+                s += '%13.2f' % rec['us_per_infected']
+            print(s)
+        return True
+
+    df, adf = simulate_individuals(v, step_callback=step_callback, callback_day_interval=a.interval, device=a.device)
+    print(adf)
+    return df, adf
+
+
+if __name__ == '__main__':
+    main()

@@ -168,5 +168,33 @@ def test_context_sample_matches_reference_distributions():
                 assert abs((got == s).mean() - (ref == s).mean()) < 0.02, (key, s)
         n += 1
     assert n == 31
+    # 'infectiousness' is advertised by the reference (main.pyx:2059,2066-2070) but calls a method
+    # Disease does not define; here it returns the (day, val) record array the caller expects
+    r = ctx.sample('infectiousness', 30)
+    assert len(r) == 200 and r['day'][0] == -100 and abs(r['val'][100] - 0.18539) < 1e-6 and r['val'][0] == 0
     with pytest.raises(Exception):
-        ctx.sample('infectiousness', 30)
+        ctx.sample('no-such-thing', 30)
+
+
+def test_scenarios_apply_like_the_reference():
+    """scenarios.py:41-53,181-190: extra interventions are appended, the 'looser' scenario halves
+    every limit-mobility reduction of the default list."""
+    from reina_model_amd import scenarios
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    base = VARIABLE_DEFAULTS['interventions']
+    v = scenarios.scenario_variables('default')
+    assert [list(i) for i in v['interventions']] == [list(i) for i in base] and v['preset_scenario'] == 'default'
+    v = scenarios.scenario_variables('mitigation')
+    assert len(v['interventions']) == len(base) + 18
+    assert v['interventions'][len(base)] == ['build-new-icu-units', '2020-06-30', 150]
+    assert v['interventions'][-1] == ['limit-mobility', '2021-02-15', 0]
+    v = scenarios.scenario_variables('hammer-and-dance')
+    assert v['interventions'][len(base)] == ['test-with-contact-tracing', '2020-05-01', 30]
+    v = scenarios.scenario_variables('looser-restrictions-to-start-with')
+    for a, b in zip(base, v['interventions']):
+        assert list(b[:2]) == list(a[:2]) and list(b[3:]) == list(a[3:])
+        if len(a) > 2:
+            assert b[2] == (a[2] // 2 if a[0] == 'limit-mobility' else a[2])
+    import pytest
+    with pytest.raises(Exception):
+        scenarios.scenario_variables('nope')
