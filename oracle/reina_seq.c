@@ -785,6 +785,49 @@ static void iterate_people(Sim *s) {
     }
 }
 
+/* Population.set_initial_state main.pyx:1452-1516 (+ get_random_person :1518-1521).  The caller
+ * passes the InitialPopulationCondition numbers (calc/datasets.py:106-134); persons are drawn
+ * WITH replacement and without any state check, exactly like the reference. */
+void seq_set_initial_state(Sim *s, int incubating, int recovered_without_illness, int ill, int dead,
+                           int in_icu, int in_ward, int were_incubating, int confirmed_cases) {
+    int i_incubating = incubating;
+    int i_recovered_without_symptoms = i_incubating + recovered_without_illness;
+    int i_ill_at_home = i_recovered_without_symptoms + ill;
+    int i_dead = i_ill_at_home + dead;
+    int i_in_icu = i_dead + in_icu;
+    int i_in_ward = i_in_icu + in_ward;
+    for (int i = 0; i < were_incubating; i++) {
+        Person *person = s->people + (int)(rp_getint(&s->rng) % (uint32_t)s->total_people);
+        person_infect(s, person, NULL, 0);
+        if (i < i_incubating) continue;
+        if (i < i_recovered_without_symptoms) {
+            person_recover(s, person);
+            continue;
+        }
+        person_become_ill(s, person);
+        if (i < i_ill_at_home) continue;
+        if (i < i_dead) {
+            person_die(s, person);
+            continue;
+        }
+        if (i < i_in_icu) {
+            person_hospitalize(s, person);
+            person_transfer_to_icu(s, person);
+            continue;
+        }
+        if (i < i_in_ward) {
+            person_hospitalize(s, person);
+            continue;
+        }
+        person_recover(s, person);
+    }
+    for (int age = 0; age < 100 && age < s->nr_ages; age++) s->cnt[C_ALL_DETECTED][age] = 0;
+    for (int i = 0; i < confirmed_cases; i++) {
+        int age = (100 + i) % 100;
+        if (age < s->nr_ages) s->cnt[C_ALL_DETECTED][age] += 1;
+    }
+}
+
 /* Context._iterate main.pyx:1994-2009; returns the problem code (iterate() raises on != 0) */
 int seq_iterate(Sim *s) {
     pop_init_day(s);

@@ -107,6 +107,7 @@ def lib():
         L.seq_set_contact_tables.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 5
         L.seq_set_testing_mode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
         L.seq_add_beds.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.seq_set_initial_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8
         L.seq_add_icu_units.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.seq_infect_people.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.seq_infect_weekly.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -200,8 +201,6 @@ class Context:
         L = lib()
         population_params = dict(population_params)
         ipc = population_params.pop('initial_population_condition', None)
-        if ipc is not None and hasattr(ipc, 'has_initial_state') and ipc.has_initial_state():
-            raise NotImplementedError('set_initial_state (main.pyx:1452-1516) is not restated yet')
         ages = population_params['age_structure']
         if hasattr(ages, 'items') and hasattr(ages, 'index'):
             nr_ages = int(ages.index.max()) + 1
@@ -253,6 +252,11 @@ class Context:
         self.day = 0
         self.interventions = []
         self._L = L
+        # main.pyx:1780-1781: the initial condition is applied last, before any intervention exists
+        if ipc is not None and ipc.has_initial_state():
+            L.seq_set_initial_state(self._h, int(ipc.incubating), int(ipc.recovered_without_illness()), int(ipc.ill),
+                                    int(ipc.dead), int(ipc.in_icu), int(ipc.in_ward), int(ipc.were_incubating()),
+                                    int(ipc.confirmed_cases))
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -407,7 +411,7 @@ def create_disease_params(variables):
     return kwargs
 
 
-def make_context(variables, age_counts, seed, interventions=None):
+def make_context(variables, age_counts, seed, interventions=None, ipc=None):
     """Build an oracle Context the way calc/simulation.py:148-180 builds the reference's."""
     from reina_model_amd import datasets
     from reina_model_amd.interventions import iv_tuple_to_obj
@@ -418,6 +422,7 @@ def make_context(variables, age_counts, seed, interventions=None):
         contacts_per_day=datasets.get_contacts_per_day(variables['country']),
         age_groups=dict(labels=groups, age_indices=[groups.index(x) for x in age_to_group]),
         imported_infection_ages=variables['imported_infection_ages'],
+        initial_population_condition=datasets.InitialPopulationCondition(**ipc) if isinstance(ipc, dict) else ipc,
     )
     hc = dict(hospital_beds=variables['hospital_beds'], icu_units=variables['icu_units'])
     ctx = Context(pop_params, hc, create_disease_params(variables), variables['start_date'], seed)

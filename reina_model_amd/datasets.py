@@ -10,6 +10,7 @@ totals, see contacts.py) is identical to the reference's melted DataFrame.
 """
 import json
 import os
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -68,3 +69,46 @@ def make_age_groups(max_age=100):
         grp = i // 10
         out.append('80+' if grp >= 8 else '%d–%d' % (grp * 10, grp * 10 + 9))
     return out
+
+
+@dataclass
+class InitialPopulationCondition:
+    """calc/datasets.py:106-134: how many people are in which state when the simulation starts."""
+    dead: int = 0
+    in_icu: int = 0
+    in_ward: int = 0
+    confirmed_cases: int = 0
+    infected_cases: int = 0
+    incubating: int = 0
+    ill: int = 0
+    recovered: int = 0
+
+    def has_initial_state(self):
+        return bool(self.dead or self.in_icu or self.in_ward or self.confirmed_cases
+                    or self.infected_cases or self.incubating or self.ill or self.recovered)
+
+    def were_incubating(self):
+        """everyone who contracted the virus at some point before the start"""
+        return sum([self.dead, self.recovered, self.in_icu, self.in_ward, self.ill, self.incubating])
+
+    def recovered_without_illness(self):
+        return self.were_incubating() - self.were_ill()
+
+    def were_ill(self):
+        return sum([self.dead, self.recovered, self.in_icu, self.in_ward, self.ill])
+
+
+def get_initial_population_condition(variables):
+    """calc/datasets.py:143-177: measured numbers (dead, in ICU, in ward, confirmed) from the
+    area's case file row of the start date, unmeasured ones from the variables; a start date the
+    file does not list means an empty initial condition (as the reference, which prints a note)."""
+    d = _load()
+    if variables['area_name'] != d['area_name']:
+        raise KeyError('no bundled case file for area %r' % variables['area_name'])
+    for row in d['case_rows']:
+        if row[0] == variables['start_date']:
+            return InitialPopulationCondition(
+                dead=row[1], in_icu=row[2], in_ward=row[3], confirmed_cases=row[4],
+                ill=variables['ill_at_simulation_start'], incubating=variables['incubating_at_simulation_start'],
+                recovered=variables['recovered_at_simulation_start'])
+    return InitialPopulationCondition()

@@ -90,7 +90,16 @@ def contacts_per_day():
     return st['simulation'].get_contacts_per_day()
 
 
-def make_context(seed, variables=None, age_structure=None, interventions='default'):
+def make_ipc(spec):
+    """dict -> the reference's InitialPopulationCondition (calc/datasets.py:106-134)"""
+    if not spec:
+        return None
+    st = setup()
+    import calc.datasets as ds
+    return ds.InitialPopulationCondition(**spec)
+
+
+def make_context(seed, variables=None, age_structure=None, interventions='default', ipc=None):
     """Build a reference `model.Context` the way calc/simulation.py:148-180 does."""
     st = setup()
     sim = st['simulation']
@@ -105,7 +114,7 @@ def make_context(seed, variables=None, age_structure=None, interventions='defaul
     pop_params = dict(
         age_structure=age_structure,
         contacts_per_day=contacts_per_day(),
-        initial_population_condition=None,
+        initial_population_condition=make_ipc(ipc),
         age_groups=dict(labels=age_groups, age_indices=[age_groups.index(x) for x in age_to_group]),
         imported_infection_ages=v['imported_infection_ages'],
     )

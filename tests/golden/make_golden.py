@@ -98,6 +98,24 @@ def scenarios():
                                              variables=dict(hospital_beds=10, icu_units=1,
                                                             p_icu_death_no_beds=60.0),
                                              interventions=KITCHEN_IVS)
+    # set_initial_state (main.pyx:1452-1516): every branch populated; a second shape where beds and
+    # ICU units run out during the initial hospitalisations
+    for seed in range(4):
+        sc['mini_initial_s%d' % seed] = dict(seed=seed, days=120, pop=20000,
+                                             variables=dict(hospital_beds=40, icu_units=6),
+                                             interventions='default',
+                                             ipc=dict(dead=5, in_icu=4, in_ward=12, confirmed_cases=230,
+                                                      incubating=60, ill=45, recovered=300))
+    for seed in range(2):
+        sc['mini_initial_full_s%d' % seed] = dict(seed=20 + seed, days=80, pop=20000,
+                                                  variables=dict(hospital_beds=9, icu_units=2,
+                                                                 p_icu_death_no_beds=50.0),
+                                                  interventions=KITCHEN_IVS,
+                                                  ipc=dict(dead=3, in_icu=6, in_ward=14, confirmed_cases=90,
+                                                           incubating=40, ill=30, recovered=100))
+    sc['hus_initial_s5'] = dict(seed=5, days=120, pop='hus', variables={}, interventions='default',
+                                ipc=dict(dead=20, in_icu=30, in_ward=80, confirmed_cases=1500,
+                                         incubating=600, ill=400, recovered=5000))
     return sc
 
 
@@ -110,7 +128,7 @@ def run_scenario(args):
     else:
         ages = mini_age_structure(spec['pop'])
     ctx = rh.make_context(spec['seed'], variables=spec['variables'], age_structure=ages,
-                          interventions=spec['interventions'])
+                          interventions=spec['interventions'], ipc=spec.get('ipc'))
     D = spec['days']
     vnames = list(ctx.disease.variant_names)
     pop = np.zeros((D, 13, 9), dtype=np.int32)
@@ -132,7 +150,7 @@ def run_scenario(args):
     ivs = rh.default_variables()['interventions'] if spec['interventions'] == 'default' \
         else spec['interventions']
     meta = dict(name=name, seed=spec['seed'], days=D, variables=spec['variables'],
-                interventions=ivs, variant_names=vnames,
+                interventions=ivs, variant_names=vnames, ipc=spec.get('ipc'),
                 age_counts=[int(x) for x in ages.values], pop13=POP13, scalars=SCALARS,
                 places=PLACES)
     out = os.path.join(HERE, name + '.npz')
@@ -181,6 +199,26 @@ def gen_inputs():
     with open(os.path.join(pkg_dir, 'fi_hus.json'), 'w') as f:
         json.dump(pkg, f)
     print('reina_model_amd/data/fi_hus.json: %d wide rows' % len(wide))
+
+
+def gen_casefile():
+    """Adds the area's case file rows (data/hosp_cases_hus.csv as the reference reads it in
+    calc/datasets.py:143-177: date -> dead, in_icu, in_ward, confirmed) to the package data."""
+    import pandas as pd
+    import ref_harness as rh
+    rh.setup()
+    import calc.datasets as ds
+    df = pd.read_csv(ds.AREA_CASEFILES['HUS'], header=0, index_col=0)
+    rows = [[str(d), int(r['dead']), int(r['in_icu']), int(r['in_ward']), int(r['confirmed'])]
+            for d, r in df.iterrows()]
+    path = os.path.join(HERE, '..', '..', 'reina_model_amd', 'data', 'fi_hus.json')
+    with open(path) as f:
+        data = json.load(f)
+    data['case_rows'] = rows
+    data['case_columns'] = ['date', 'dead', 'in_icu', 'in_ward', 'confirmed']
+    with open(path, 'w') as f:
+        json.dump(data, f)
+    print('fi_hus.json: %d case rows (%s .. %s)' % (len(rows), rows[0][0], rows[-1][0]))
 
 
 def gen_rng_kat():
@@ -259,6 +297,7 @@ def main():
     rh.setup()  # build the extension once before forking workers
     if not a.skip_aux and not a.only:
         gen_inputs()
+        gen_casefile()
         gen_rng_kat()
         gen_samples()
     sc = scenarios()

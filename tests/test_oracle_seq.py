@@ -14,7 +14,7 @@ from oracle import seq_oracle as so
 def _run_and_compare(name, max_days=None):
     z, meta = load_run(name)
     ctx = so.make_context(variables_for(meta), meta['age_counts'], meta['seed'],
-                          interventions=meta['interventions'])
+                          interventions=meta['interventions'], ipc=meta.get('ipc'))
     days = meta['days'] if max_days is None else min(max_days, meta['days'])
     for d in range(days):
         compare_day(ctx.generate_state(), z, meta, d)
@@ -42,6 +42,18 @@ def test_mini_kitchen_sink_bit_exact(name):
     """Every intervention type incl. vaccination, new beds/ICU, variant imports, weekly variant
     shares, p_icu_death_no_beds < 1 (ICU accounting drift, quirk Q7)."""
     _run_and_compare(name)
+
+
+@pytest.mark.parametrize('name', ['mini_initial_s%d' % s for s in range(4)] + ['mini_initial_full_s0', 'mini_initial_full_s1'])
+def test_initial_population_condition_bit_exact(name):
+    """Population.set_initial_state (main.pyx:1452-1516): people incubating / ill / in ward / in ICU
+    / dead / recovered at the start, confirmed cases spread over ages; the `_full` runs exhaust
+    beds and ICU units during the initial hospitalisations."""
+    _run_and_compare(name)
+
+
+def test_hus_initial_condition_first_40_days_bit_exact():
+    _run_and_compare('hus_initial_s5', max_days=40)
 
 
 @pytest.mark.slow
