@@ -213,6 +213,21 @@ typedef struct {
                                          (= generate_state() taken before iterate(), simulation.py:195) */
 } reina_day_t;
 
+/* InitialPopulationCondition of the reference (calc/datasets.py:106-134) in the order
+ * Population.set_initial_state walks it (main.pyx:1452-1516): slot i of [0, were_incubating) is
+ * infected, then by rank: [0, incubating) stays incubating; the next recovered_without_illness
+ * recover at once; everyone after falls ill, of whom the next `ill` stay ill at home, the next `dead`
+ * die, the next `in_icu` are hospitalised and moved to ICU, the next `in_ward` hospitalised, the
+ * rest recover.  Then all_detected[0..99] is reset and confirmed_cases are spread round-robin over
+ * those ages.  (A sharded population gives every shard its share of each number.) */
+typedef struct {
+    uint32_t incubating, recovered_without_illness, ill, dead, in_icu, in_ward;
+    uint32_t were_incubating;   /* total slots */
+    uint32_t confirmed_cases;
+    uint32_t confirmed_first;   /* shards: this shard owns confirmed cases first, first+stride, ... */
+    uint32_t confirmed_stride;  /* 1 for an unsharded population */
+} reina_initial_state_t;
+
 typedef struct reina_engine reina_engine_t;
 typedef struct reina_group reina_group_t;
 
@@ -224,6 +239,11 @@ int reina_destroy(reina_engine_t *e);
  * (main.pyx:1389-1450): all susceptible, counters = age histogram, beds/ICU free */
 int reina_bind_buffers(reina_engine_t *e, const reina_buffers_t *buffers);
 int reina_init_state(reina_engine_t *e, int32_t hospital_beds, int32_t icu_units, void *stream);
+/* replaces Population.set_initial_state (main.pyx:1452-1516); call once, right after
+ * reina_init_state and before the first day.  Parallel form: every slot draws a uniform agent (up
+ * to 10 tries for a never-infected one, lowest slot wins a contested agent) instead of the
+ * reference's draw with replacement; beds and ICU units are granted in slot order. */
+int reina_set_initial_state(reina_engine_t *e, const reina_initial_state_t *ic, void *stream);
 /* replaces ContactMatrix.generate_contact_probabilities upload (main.pyx:1184-1235) */
 int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t *t, void *stream);
 /* replaces Context.iterate() for one day (main.pyx:2011-2018) */

@@ -425,17 +425,23 @@ static void emit_event(Par *e, uint32_t i, uint32_t day, int type) {
 
 /* person_become_ill (main.pyx:284-291) + get_days_from_onset_to_removed / get_illness_days
  * (:989-1014) + HealthcareSystem.seek_testing (:595-615) */
-static uint32_t become_ill(Par *e, uint32_t i, uint32_t w, const reina_day_t *dp) {
+static uint32_t onset_word(Par *e, uint32_t i, uint32_t w, uint32_t day) {
     int v = RH_VARIANT(w), sev = RH_SEV(w);
     float mu = sev == RV_FATAL ? e->dis.mean_duration_from_onset_to_death[v]
                                : e->dis.mean_duration_from_onset_to_recovery[v];
-    float d = rp_gamma_mu_cv(mu, 0.45f, e->k0, e->k1, i, dp->day, RP_P_ONSET, 1);
+    float d = rp_gamma_mu_cv(mu, 0.45f, e->k0, e->k1, i, day, RP_P_ONSET, 1);
     e->buf.onset_days[i] = d;
     float f = d;
     if (sev >= RV_SEVERE) f *= e->dis.ratio_of_duration_before_hospitalisation[v];
     w = RH_SET_STATE(w, RS_ILLNESS);
     w = RH_SET_DAYS_LEFT(w, clamp_days(e, rp_round_to_int(f)));
     w = RH_SET_DOI(w, 0);
+    return w;
+}
+
+static uint32_t become_ill(Par *e, uint32_t i, uint32_t w, const reina_day_t *dp) {
+    int sev = RH_SEV(w);
+    w = onset_word(e, i, w, dp->day);
     if (sev != RV_ASYMPTOMATIC && !(w & RH_DETECTED)) {
         int q = 0;
         if (dp->testing_mode == RT_ALL_WITH_SYMPTOMS || dp->testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
@@ -632,6 +638,125 @@ static void run_hospital(Par *e, const reina_day_t *dp) {
     }
     SC(e, REINA_S_AVAILABLE_BEDS) = b;
     SC(e, REINA_S_AVAILABLE_ICU) = c;
+}
+
+/* ---------------------------------------------------------------- initial population condition */
+/* Population.set_initial_state (main.pyx:1452-1516), parallel form (include/reina_hip.h:
+ * reina_set_initial_state).  Every slot owns up to 10 target draws keyed (slot, RP_INIT_DAY, try);
+ * a contested agent goes to the lowest slot.  Capacity: ICU-fated slots come first and hand their
+ * bed back when they move to ICU (hc.to_icu, main.pyx:641-646), so the r-th ICU slot gets a unit iff
+ * r < units and the r-th ward slot a bed iff r < beds.  Not reproduced: the reference's second
+ * visit of an agent drawn twice, and its transfer_to_icu of an agent who was just refused a bed
+ * (only reachable with zero beds). */
+static int initial_target(Par *e, uint32_t slot, uint32_t k, uint32_t *t_out) {
+    rp_u4 r = rp_philox(e->k0, e->k1, slot, RP_INIT_DAY, RP_P_INITIAL, k);
+    *t_out = r.v[0] % e->cfg.n_agents;
+    return 1;
+}
+
+int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream) {
+    (void)stream;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    const uint32_t M = ic->were_incubating;
+    const uint32_t i_inc = ic->incubating, i_rec = i_inc + ic->recovered_without_illness, i_ill = i_rec + ic->ill,
+                   i_dead = i_ill + ic->dead, i_icu = i_dead + ic->in_icu, i_ward = i_icu + ic->in_ward;
+    const reina_disease_t *d = &e->dis;
+    uint32_t *target = (uint32_t *)malloc(sizeof(uint32_t) * (M + 1));
+    uint8_t *next_try = (uint8_t *)calloc(M + 1, 1);
+    int b = SC(e, REINA_S_AVAILABLE_BEDS), c = SC(e, REINA_S_AVAILABLE_ICU);
+    const int beds0 = b, icu0 = c;
+    /* slots are worked off in chunks of 16384 (the HIP kernel's LDS bookkeeping), rounds per chunk */
+    for (uint32_t c0 = 0; c0 < M; c0 += 16384u) {
+    const uint32_t c1 = M - c0 < 16384u ? M : c0 + 16384u;
+    for (uint32_t round = 0; round < 10; round++) {
+        uint32_t proposals = 0;
+        for (uint32_t j = c0; j < c1; j++) {
+            target[j] = 0xFFFFFFFFu;
+            if (next_try[j] == 255) continue;
+            uint32_t k = next_try[j];
+            for (; k < 10; k++) {
+                uint32_t t;
+                if (initial_target(e, j, k, &t) && RH_STATE(e->buf.hot[t]) == RS_SUSCEPTIBLE) {
+                    target[j] = t;
+                    break;
+                }
+            }
+            next_try[j] = (uint8_t)(k < 10 ? k + 1 : 10);
+            if (target[j] != 0xFFFFFFFFu) proposals++;
+        }
+        if (!proposals) break;
+        for (uint32_t j = c0; j < c1; j++) {
+            if (target[j] == 0xFFFFFFFFu) continue;
+            uint64_t key = rp_order_key(0, 0xFFFFFu - round, j);
+            if (key < e->buf.claim[target[j]]) e->buf.claim[target[j]] = key;
+        }
+        for (uint32_t j = c0; j < c1; j++) {
+            if (target[j] == 0xFFFFFFFFu) continue;
+            const uint32_t t = target[j];
+            if (e->buf.claim[t] != rp_order_key(0, 0xFFFFFu - round, j)) continue;
+            next_try[j] = 255;
+            install_infection(e, t, RP_INIT_DAY, 0, -1, j < i_inc, RT_NO_TESTING);
+            if (j < i_inc) continue;
+            uint32_t w = e->buf.hot[t];
+            const int age = age_of(e, t);
+            if (j < i_rec) {
+                e->buf.hot[t] = do_recover(e, w, age);
+                continue;
+            }
+            w = onset_word(e, t, w, RP_INIT_DAY);
+            const int v = RH_VARIANT(w), sev = RH_SEV(w);
+            const float od = e->buf.onset_days[t];
+            if (j < i_ill) {
+            } else if (j < i_dead) {
+                w = do_die(e, w, age);
+            } else if (j < i_ward) {
+                const int to_icu = j < i_icu;
+                w |= RH_DETECTED;   /* person_hospitalize detects first (main.pyx:322-325) */
+                CNT(e, REINA_C_DETECTED, age) += 1;
+                CNT(e, REINA_C_ALL_DETECTED, age) += 1;
+                const int bed = to_icu ? beds0 > 0 : (int)(j - i_icu) < beds0;
+                if (!bed) {
+                    w = dies_in_hospital(e, t, RP_INIT_DAY, sev, v, 0) ? do_die(e, w, age) : do_recover(e, w, age);
+                } else if (!to_icu) {
+                    b--;
+                    float f = sev == RV_SEVERE ? od * (1.0f - d->ratio_of_duration_before_hospitalisation[v])
+                                               : od * d->ratio_of_duration_in_ward[v];
+                    w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)));
+                    CNT(e, REINA_C_HOSPITALIZED, age) += 1;
+                    CNT(e, REINA_C_IN_WARD, age) += 1;
+                } else {
+                    const int unit = (int)(j - i_dead) < icu0;
+                    if (unit) c--;
+                    if (!unit && dies_in_hospital(e, t, RP_INIT_DAY, sev, v, 0)) {
+                        w = do_die(e, w, age);   /* hospitalised and released at once: no net ward count */
+                    } else {
+                        float f = 1.0f - d->ratio_of_duration_in_ward[v] - d->ratio_of_duration_before_hospitalisation[v];
+                        f *= od;
+                        w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)));
+                        CNT(e, REINA_C_HOSPITALIZED, age) += 1;
+                        CNT(e, REINA_C_IN_ICU, age) += 1;
+                        CNT(e, REINA_C_CUM_ICU, age) += 1;
+                    }
+                }
+            } else {
+                w = do_recover(e, w, age);
+            }
+            e->buf.hot[t] = w;
+        }
+    }
+    }
+    for (uint32_t j = 0; j < M; j++)
+        if (next_try[j] != 255) SC(e, REINA_S_UNABLE_TO_IMPORT) += 1;
+    SC(e, REINA_S_AVAILABLE_BEDS) = b;
+    SC(e, REINA_S_AVAILABLE_ICU) = c;
+    /* main.pyx:1503-1516 */
+    for (uint32_t a = 0; a < 100 && a < e->cfg.nr_ages; a++) CNT(e, REINA_C_ALL_DETECTED, a) = 0;
+    const uint32_t stride = ic->confirmed_stride ? ic->confirmed_stride : 1;
+    for (uint32_t i = ic->confirmed_first; i < ic->confirmed_cases; i += stride)
+        if (i % 100 < e->cfg.nr_ages) CNT(e, REINA_C_ALL_DETECTED, i % 100) += 1;
+    free(target);
+    free(next_try);
+    return 0;
 }
 
 /* ---------------------------------------------------------------- contacts + install */

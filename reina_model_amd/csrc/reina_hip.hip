@@ -681,17 +681,24 @@ __host__ __device__ __forceinline__ uint32_t scan_slice_base(uint32_t sw, uint32
 
 // person_become_ill (main.pyx:284-291, 989-1014) + seek_testing (:595-615); `w` already carries
 // days_left == 0 from the countdown
-__device__ void become_ill(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, uint32_t i, uint32_t w) {
+// person_become_ill's durations (main.pyx:284-288,989-1014): onset->removed gamma, illness days
+__device__ __forceinline__ uint32_t onset_word(const DevParams *P, const reina_buffers_t &B, uint32_t i, uint32_t w, uint32_t day) {
     const reina_disease_t &d = P->dis;
     int v = RH_VARIANT(w), sev = RH_SEV(w);
     float mu = sev == RV_FATAL ? d.mean_duration_from_onset_to_death[v] : d.mean_duration_from_onset_to_recovery[v];
-    float od = rp_gamma_mu_cv(mu, 0.45f, P->k0, P->k1, i, dp.day, RP_P_ONSET, 1);
+    float od = rp_gamma_mu_cv(mu, 0.45f, P->k0, P->k1, i, day, RP_P_ONSET, 1);
     B.onset_days[i] = od;
     float f = od;
     if (sev >= RV_SEVERE) f *= d.ratio_of_duration_before_hospitalisation[v];
     w = RH_SET_STATE(w, RS_ILLNESS);
     w = RH_SET_DAYS_LEFT(w, clamp_days(B.counters, rp_round_to_int(f)));
     w = RH_SET_DOI(w, 0);
+    return w;
+}
+
+__device__ void become_ill(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, uint32_t i, uint32_t w) {
+    const int sev = RH_SEV(w);
+    w = onset_word(P, B, i, w, dp.day);
     if (sev != RV_ASYMPTOMATIC && !(w & RH_DETECTED)) {
         int q = 0;
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS || dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
@@ -1216,6 +1223,162 @@ __global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const MemberRef *M_, 
     if (tid == 0) {
         B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] = s_b;
         B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] = s_c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_initial_state: Population.set_initial_state (main.pyx:1452-1516), parallel form (see
+// include/reina_hip.h: reina_set_initial_state and oracle/reina_par.c: par_set_initial_state).
+// One workgroup; slots in chunks of PRO_MAX_IMPORTS; per chunk the propose / claim / resolve
+// rounds of the import placement, then the slot's fate applied by the winning lane.
+__global__ __launch_bounds__(PRO_THREADS) void k_initial_state(const MemberRef *M_, reina_initial_state_t ic) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t B = mref_.B;
+    __shared__ uint8_t placed[PRO_MAX_IMPORTS];
+    __shared__ int32_t s_cnt[HL_NR][REINA_MAX_AGES];
+    __shared__ int32_t new_by_age[REINA_MAX_AGES];
+    __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
+    __shared__ int32_t s_beds_used, s_icu_used, s_unplaced;
+    const int tid = threadIdx.x;
+    if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
+    if (tid < REINA_MAX_AGES) new_by_age[tid] = 0;
+    if (tid < REINA_MAX_VARIANTS) new_by_variant[tid] = 0;
+    for (int k = tid; k < HL_NR * REINA_MAX_AGES; k += PRO_THREADS) (&s_cnt[0][0])[k] = 0;
+    if (tid == 0) s_beds_used = s_icu_used = s_unplaced = 0;
+    __syncthreads();
+    const reina_disease_t &d = P->dis;
+    const uint32_t N = P->n_agents, M = ic.were_incubating;
+    const uint32_t i_inc = ic.incubating, i_rec = i_inc + ic.recovered_without_illness, i_ill = i_rec + ic.ill,
+                   i_dead = i_ill + ic.dead, i_icu = i_dead + ic.in_icu, i_ward = i_icu + ic.in_ward;
+    const int beds0 = B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)], icu0 = B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)];
+    for (uint32_t c0 = 0; c0 < M; c0 += PRO_MAX_IMPORTS) {
+        const uint32_t total = M - c0 < PRO_MAX_IMPORTS ? M - c0 : PRO_MAX_IMPORTS;
+        for (uint32_t j = tid; j < total; j += PRO_THREADS) placed[j] = 0;
+        __syncthreads();
+        for (uint32_t round = 0; round < 10; round++) {
+            int proposals = 0;
+            for (uint32_t j = tid; j < total; j += PRO_THREADS) {
+                if (placed[j] == 255) continue;
+                uint32_t k = placed[j], t = 0;
+                bool found = false;
+                for (; k < 10; k++) {
+                    t = rp_philox(P->k0, P->k1, c0 + j, RP_INIT_DAY, RP_P_INITIAL, k).v[0] % N;
+                    if (RH_STATE(ld_hot(&B.hot[t])) == RS_SUSCEPTIBLE) {
+                        found = true;
+                        break;
+                    }
+                }
+                if (found) {
+                    atomicMin((unsigned long long *)&B.claim[t], (unsigned long long)rp_order_key(0, 0xFFFFFu - round, c0 + j));
+                    placed[j] = (uint8_t)(0x80u | k);
+                    proposals++;
+                } else {
+                    placed[j] = 10;
+                }
+            }
+            if (__syncthreads_or(proposals) == 0) break;
+            for (uint32_t j = tid; j < total; j += PRO_THREADS) {
+                const uint8_t st = placed[j];
+                if (st == 255 || !(st & 0x80u)) continue;
+                const uint32_t k = st & 0x7Fu, slot = c0 + j;
+                const uint32_t t = rp_philox(P->k0, P->k1, slot, RP_INIT_DAY, RP_P_INITIAL, k).v[0] % N;
+                placed[j] = (uint8_t)(k + 1);
+                if (ld_claim(&B.claim[t]) != rp_order_key(0, 0xFFFFFu - round, slot)) continue;
+                placed[j] = 255;
+                uint32_t w = ld_hot(&B.hot[t]);
+                if (!install_infection(P, B, s_age_start, t, w, RP_INIT_DAY, 0, -1, slot < i_inc, RT_NO_TESTING, new_by_age, new_by_variant))
+                    continue;
+                if (slot < i_inc) continue;
+                w = ld_hot(&B.hot[t]);
+                const int age = age_of(s_age_start, t, 0, (int)P->nr_ages - 1);
+                int died = -1;  // -1 keeps the state set below, 0 recovers, 1 dies
+                if (slot < i_rec) {
+                    died = 0;
+                } else {
+                    w = onset_word(P, B, t, w, RP_INIT_DAY);
+                    const int v = RH_VARIANT(w), sev = RH_SEV(w);
+                    const float od = B.onset_days[t];
+                    if (slot < i_ill) {
+                    } else if (slot < i_dead) {
+                        died = 1;
+                    } else if (slot < i_ward) {
+                        const bool to_icu = slot < i_icu;
+                        w |= RH_DETECTED;
+                        atomicAdd(&s_cnt[HL_DETECTED][age], 1);
+                        atomicAdd(&s_cnt[HL_ALL_DETECTED][age], 1);
+                        const bool bed = to_icu ? beds0 > 0 : (int)(slot - i_icu) < beds0;
+                        if (!bed) {
+                            died = dies_in_hospital(P, t, RP_INIT_DAY, sev, v, 0);
+                        } else if (!to_icu) {
+                            atomicAdd(&s_beds_used, 1);
+                            float f = sev == RV_SEVERE ? od * (1.0f - d.ratio_of_duration_before_hospitalisation[v])
+                                                       : od * d.ratio_of_duration_in_ward[v];
+                            w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(B.counters, rp_round_to_int(f)));
+                            atomicAdd(&s_cnt[HL_HOSPITALIZED][age], 1);
+                            atomicAdd(&s_cnt[HL_IN_WARD][age], 1);
+                        } else {
+                            const bool unit = (int)(slot - i_dead) < icu0;
+                            if (unit) atomicAdd(&s_icu_used, 1);
+                            if (!unit && dies_in_hospital(P, t, RP_INIT_DAY, sev, v, 0)) {
+                                died = 1;
+                            } else {
+                                float f = 1.0f - d.ratio_of_duration_in_ward[v] - d.ratio_of_duration_before_hospitalisation[v];
+                                f *= od;
+                                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(B.counters, rp_round_to_int(f)));
+                                atomicAdd(&s_cnt[HL_HOSPITALIZED][age], 1);
+                                atomicAdd(&s_cnt[HL_IN_ICU][age], 1);
+                                atomicAdd(&s_cnt[HL_CUM_ICU][age], 1);
+                            }
+                        }
+                    } else {
+                        died = 0;
+                    }
+                }
+                if (died == 1) {
+                    atomicAdd(&s_cnt[HL_INFECTED][age], -1);
+                    atomicAdd(&s_cnt[HL_DEAD][age], 1);
+                    if (w & RH_POD_OUTSIDE) atomicAdd(&s_cnt[HL_NHD][age], 1);
+                    w = RH_SET_STATE(w, RS_DEAD) & ~RH_HASLIST;
+                } else if (died == 0) {
+                    atomicAdd(&s_cnt[HL_INFECTED][age], -1);
+                    atomicAdd(&s_cnt[HL_RECOVERED][age], 1);
+                    w = RH_SET_STATE(w, RS_RECOVERED) & ~RH_HASLIST;
+                }
+                B.hot[t] = w;
+            }
+            __syncthreads();
+        }
+        int mine = 0;
+        for (uint32_t j = tid; j < total; j += PRO_THREADS)
+            if (placed[j] != 255) mine++;
+        if (mine) atomicAdd(&s_unplaced, mine);
+        __syncthreads();
+    }
+    flush_new_infections(B, new_by_age, new_by_variant, PRO_THREADS);
+    // per-age counters; all_detected[0..99] restarts from the confirmed cases (main.pyx:1503-1516)
+    const uint32_t stride = ic.confirmed_stride ? ic.confirmed_stride : 1u;
+    for (int k = tid; k < HL_NR * REINA_MAX_AGES; k += PRO_THREADS) {
+        const int what = k / REINA_MAX_AGES, age = k % REINA_MAX_AGES;
+        const int map[HL_NR] = {REINA_C_INFECTED, REINA_C_DETECTED, REINA_C_ALL_DETECTED, REINA_C_HOSPITALIZED,
+                                REINA_C_IN_WARD, REINA_C_IN_ICU, REINA_C_CUM_ICU, REINA_C_DEAD,
+                                REINA_C_NON_HOSPITAL_DEATHS, REINA_C_RECOVERED};
+        int32_t v = (&s_cnt[0][0])[k];
+        if (what == HL_ALL_DETECTED && age < 100 && age < (int)P->nr_ages) {
+            // confirmed cases first, first+stride, ... < confirmed_cases with index % 100 == age
+            int32_t n = 0;
+            for (uint32_t i = ic.confirmed_first; i < ic.confirmed_cases; i += stride)
+                if ((int)(i % 100u) == age) n++;
+            B.counters[CNT_IDX(REINA_C_ALL_DETECTED, age)] = n;
+        } else if (v) {
+            B.counters[CNT_IDX(map[what], age)] += v;
+        }
+    }
+    if (tid == 0) {
+        B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] = beds0 - s_beds_used;
+        B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] = icu0 - s_icu_used;
+        if (s_unplaced) B.counters[SC_IDX(REINA_S_UNABLE_TO_IMPORT)] += s_unplaced;
     }
 }
 
@@ -1862,6 +2025,14 @@ int reina_init_state(reina_engine_t *e, int32_t beds, int32_t icu, void *stream)
     if (!e || !e->bound) return REINA_E_NOT_BOUND;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_init, dim3(grid_for(e->cfg.n_agents, 256, 4096), 1), dim3(256), 0, s, e->d_ref, beds, icu);
+    HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+
+int reina_set_initial_state(reina_engine_t *e, const reina_initial_state_t *ic, void *stream) {
+    if (!e || !ic) return REINA_E_INVALID;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    hipLaunchKernelGGL(k_initial_state, dim3(1, 1), dim3(PRO_THREADS), 0, (hipStream_t)stream, e->d_ref, *ic);
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }

@@ -72,7 +72,8 @@ enum {
     RP_P_IMPORT = 7,      // (import #, day, c3 = try): age class, target
     RP_P_PRIORITY = 8,    // (agent, day): order key for scarce resources / winner selection
     RP_P_REMOTE = 9,      // (attempt #, day, c3 = range | variant << 8): realisation of cross-shard pressure
-    RP_P_MIRROR = 10      // (agent, day, c3 = contact #): slot + tie-break of an outgoing attempt in the mirror table
+    RP_P_MIRROR = 10,     // (agent, day, c3 = contact #): slot + tie-break of an outgoing attempt in the mirror table
+    RP_P_INITIAL = 11     // (slot, RP_INIT_DAY, c3 = try): agent of an initial-condition slot
 };
 
 // uniform in [0,1) with 24 random bits: exact in float
@@ -235,6 +236,9 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 enum { RS_SUSCEPTIBLE = 0, RS_INCUBATION, RS_ILLNESS, RS_HOSPITALIZED, RS_IN_ICU, RS_RECOVERED, RS_DEAD };
 enum { RV_ASYMPTOMATIC = 0, RV_MILD, RV_SEVERE, RV_CRITICAL, RV_FATAL };
 enum { RT_NO_TESTING = 0, RT_ALL_WITH_SYMPTOMS_CT, RT_ALL_WITH_SYMPTOMS, RT_ONLY_SEVERE_SYMPTOMS };
+
+// "day" of every draw made while the initial population condition is applied (before day 0)
+#define RP_INIT_DAY 0xFFFFFFFFu
 
 // claim / ordering key: smaller wins. [4095-day : 12][priority : 20][id : 32]
 RP_HD uint64_t rp_order_key(uint32_t day, uint32_t prio20, uint32_t id) {

@@ -43,7 +43,7 @@ S_NR = 32
 COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 32
 
-ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'upload_contact_tables',
+ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
                  'step_day', 'step_day_begin', 'step_day_end', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
                  'group_create', 'group_destroy', 'group_upload_contact_tables', 'group_run_days',
                  'last_error', 'abi_version')
@@ -96,6 +96,12 @@ class Buffers(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in BUFFER_FIELDS]
 
 
+class InitialState(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in (
+        'incubating', 'recovered_without_illness', 'ill', 'dead', 'in_icu', 'in_ward', 'were_incubating',
+        'confirmed_cases', 'confirmed_first', 'confirmed_stride')]
+
+
 class ImportBatch(ctypes.Structure):
     _fields_ = [('count', ctypes.c_uint32), ('variant', ctypes.c_uint32),
                 ('pre_init', ctypes.c_uint32), ('reserved', ctypes.c_uint32)]
@@ -126,6 +132,7 @@ def bind_abi(lib, prefix):
     f['destroy'].argtypes = [vp]
     f['bind_buffers'].argtypes = [vp, ctypes.POINTER(Buffers)]
     f['init_state'].argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp]
+    f['set_initial_state'].argtypes = [vp, ctypes.POINTER(InitialState), vp]
     f['upload_contact_tables'].argtypes = [vp, ctypes.POINTER(ContactTablesABI), vp]
     f['step_day'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['step_day_begin'].argtypes = [vp, ctypes.POINTER(Day), vp]
@@ -259,6 +266,9 @@ class Engine:
             t.range_min[k] = int(lo)
             t.range_max[k] = int(hi)
         return t, arrs
+
+    def set_initial_state(self, ic):
+        self._check(self.f['set_initial_state'](self._h, ctypes.byref(ic), self.alloc.stream()), 'set_initial_state')
 
     def upload_contact_tables(self, nrc, count, threshold, meta, mask_p, ranges):
         t, _keep = self._tables_abi(nrc, count, threshold, meta, mask_p, ranges)

@@ -207,8 +207,6 @@ class Context:
         self._split = lambda x: split_count(x, self.shard_rank, self.n_shards)
         population_params = dict(population_params)
         ipc = population_params.pop('initial_population_condition', None)
-        if ipc is not None and hasattr(ipc, 'has_initial_state') and ipc.has_initial_state():
-            raise NotImplementedError('set_initial_state (main.pyx:1452-1516) is not supported yet')
 
         ages = population_params['age_structure']
         if hasattr(ages, 'items') and hasattr(ages, 'index'):
@@ -292,6 +290,29 @@ class Context:
         self._pending_icu = 0
         self._keep = []
         self._iv_index = None
+        # main.pyx:1780-1781: the initial condition is applied last, before any intervention exists
+        if ipc is not None and ipc.has_initial_state():
+            self._set_initial_state(ipc)
+
+    def _set_initial_state(self, ipc):
+        """Population.set_initial_state (main.pyx:1452-1516) on the engine; a sharded population
+        applies each shard's share of every number."""
+        ic = _eng.InitialState()
+        sp = self._split
+        ic.incubating = sp(int(ipc.incubating))
+        ic.recovered_without_illness = sp(int(ipc.recovered_without_illness()))
+        ic.ill = sp(int(ipc.ill))
+        ic.dead = sp(int(ipc.dead))
+        ic.in_icu = sp(int(ipc.in_icu))
+        ic.in_ward = sp(int(ipc.in_ward))
+        rest = sp(int(ipc.were_incubating()) - int(ipc.incubating) - int(ipc.recovered_without_illness())
+                  - int(ipc.ill) - int(ipc.dead) - int(ipc.in_icu) - int(ipc.in_ward))
+        ic.were_incubating = (ic.incubating + ic.recovered_without_illness + ic.ill + ic.dead + ic.in_icu
+                              + ic.in_ward + max(rest, 0))
+        ic.confirmed_cases = int(ipc.confirmed_cases)
+        ic.confirmed_first = self.shard_rank
+        ic.confirmed_stride = self.n_shards
+        self.engine.set_initial_state(ic)
 
     # ------------------------------------------------------------------ host helpers
     def _packed_tables(self):

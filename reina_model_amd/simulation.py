@@ -53,7 +53,7 @@ def create_disease_params(variables):
 
 
 def make_context(variables, age_counts=None, seed=None, interventions=None, device='cuda:0',
-                 engine_factory=None, comm=None):
+                 engine_factory=None, comm=None, ipc=None):
     """Build a Context the way calc/simulation.py:148-180 does."""
     if age_counts is None:
         age_counts = datasets.get_population_for_area(variables['area_name'])
@@ -62,7 +62,7 @@ def make_context(variables, age_counts=None, seed=None, interventions=None, devi
     pop_params = dict(
         age_structure=np.asarray(age_counts),
         contacts_per_day=datasets.get_contacts_per_day(variables['country']),
-        initial_population_condition=None,
+        initial_population_condition=datasets.InitialPopulationCondition(**ipc) if isinstance(ipc, dict) else ipc,
         age_groups=dict(labels=groups, age_indices=[groups.index(x) for x in age_to_group]),
         imported_infection_ages=variables['imported_infection_ages'],
     )
@@ -86,7 +86,8 @@ def simulate_individuals(variables=None, step_callback=None, callback_day_interv
     if variables is None:
         variables = copy_variables()
     t0 = time.perf_counter()
-    ctx = make_context(variables, age_counts=age_counts, device=device, engine_factory=engine_factory)
+    ctx = make_context(variables, age_counts=age_counts, device=device, engine_factory=engine_factory,
+                       ipc=datasets.get_initial_population_condition(variables))   # calc/simulation.py:152
     start_date = date.fromisoformat(variables['start_date'])
     days = variables['simulation_days']
     age_groups = ctx.age_group_labels

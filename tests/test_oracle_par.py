@@ -150,3 +150,29 @@ def test_driver_sample_model_parameters_and_monte_carlo(tmp_path, monkeypatch):
     got = df[df['run'] == 1].set_index('date')
     for col in ('infected', 'all_infected', 'susceptible', 'exposures_home', 'r'):
         assert np.array_equal(got[col].values, one[col].values), col
+
+
+def test_initial_condition_on_a_sharded_population():
+    """every shard applies its share of each InitialPopulationCondition number; the global counters
+    add up to the unsharded totals (all_detected is rebuilt from the confirmed cases)"""
+    import copy
+    import numpy as np
+    import par_backend
+    from reina_model_amd import datasets, engine as eng, sharding, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=40, icu_units=9)
+    ages = datasets.scaled_population(30000)
+    ipc = dict(dead=7, in_icu=5, in_ward=11, confirmed_cases=123, incubating=50, ill=31, recovered=200)
+    G, A = 3, eng.MAX_AGES
+    members = []
+    ctxs = [simulation.make_context(v, age_counts=ages, seed=4, ipc=ipc, engine_factory=par_backend.par_engine_factory,
+                                    comm=sharding.InProcessComm(r, G, members)) for r in range(G)]
+    c = sharding.reduce_counters(ctxs)
+    tot = lambda name: int(c[eng.C_NAMES.index(name) * A:(eng.C_NAMES.index(name) + 1) * A].sum())
+    assert tot('all_infected') == 7 + 5 + 11 + 50 + 31 + 200
+    assert tot('all_detected') == 123
+    assert tot('dead') >= 7 and tot('in_icu') <= 5 and tot('in_ward') == 11
+    assert tot('infected') + tot('recovered') + tot('dead') == tot('all_infected')
+    for _ in range(5):
+        sharding.step_shards_together(ctxs)

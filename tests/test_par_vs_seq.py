@@ -95,3 +95,37 @@ def test_sharded_formulation_matches_sequential_oracle_statistically():
 def test_hip_engine_matches_sequential_oracle_statistically():
     runs, z, attrs = _ensemble()
     _check(runs, z, attrs)
+
+
+def test_initial_condition_parallel_form_matches_sequential_oracle():
+    """set_initial_state: the parallel form (distinct agents, slot-ordered capacity) against the
+    sequential restatement (draws with replacement), 24 seeds each, right after construction and on
+    days 15 / 30; same tolerance as above."""
+    import par_backend
+    from oracle import seq_oracle as so
+    from reina_model_amd import datasets, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=9, icu_units=2, p_icu_death_no_beds=50.0)
+    ages = datasets.scaled_population(60000)
+    ipc = dict(dead=30, in_icu=12, in_ward=20, confirmed_cases=230, incubating=200, ill=150, recovered=900)
+    names = ['susceptible', 'infected', 'all_infected', 'recovered', 'dead', 'in_ward', 'in_icu', 'detected',
+             'all_detected', 'available_hospital_beds', 'available_icu_units']
+
+    def series(ctx):
+        out = []
+        for d in range(31):
+            if d in (0, 15, 30):
+                s = ctx.generate_state()
+                out.append([float(np.sum(s[n])) for n in names])
+            ctx.iterate()
+        return out
+
+    A = np.array([series(so.make_context(v, ages, seed, ipc=ipc)) for seed in range(24)])
+    B = np.array([series(simulation.make_context(v, age_counts=ages, seed=seed, ipc=ipc,
+                                                 engine_factory=par_backend.par_engine_factory)) for seed in range(100, 124)])
+    for d in range(3):
+        for k, n in enumerate(names):
+            se = np.sqrt(A[:, d, k].var(ddof=1) / 24 + B[:, d, k].var(ddof=1) / 24)
+            tol = 4.0 * se + 0.005 * abs(A[:, d, k].mean()) + 1.0
+            assert abs(A[:, d, k].mean() - B[:, d, k].mean()) <= tol, (d, n, A[:, d, k].mean(), B[:, d, k].mean(), tol)

@@ -293,3 +293,28 @@ def test_run_ensemble_batched_equals_threaded():
     a = ensemble.run_ensemble(v, range(6), 120, age_counts=ages, batched=True, concurrent=4)
     b = ensemble.run_ensemble(v, range(6), 120, age_counts=ages, batched=False)
     assert np.array_equal(a, b)
+
+
+IPC = dict(dead=30, in_icu=12, in_ward=20, confirmed_cases=230, incubating=200, ill=150, recovered=900)
+
+
+@pytest.mark.parametrize('beds,icu,n,ipc', [(9, 2, 60000, IPC), (2600, 300, 60000, IPC),
+                                             (30, 5, 300000, dict(dead=300, in_icu=40, in_ward=90, confirmed_cases=4000,
+                                                                  incubating=6000, ill=4000, recovered=12000))])
+def test_initial_population_condition(beds, icu, n, ipc):
+    """reina_set_initial_state (Population.set_initial_state, main.pyx:1452-1516): state right after
+    construction and the following days, HIP == oracle B bit for bit; the third case needs two slot
+    chunks and fills 20 % of a small age class."""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=beds, icu_units=icu, p_icu_death_no_beds=50.0)
+    ages = datasets.scaled_population(n)
+    import par_backend
+    gpu = simulation.make_context(v, age_counts=ages, seed=9, ipc=ipc)
+    cpu = simulation.make_context(v, age_counts=ages, seed=9, ipc=ipc, engine_factory=par_backend.par_engine_factory)
+    assert np.array_equal(gpu.engine.read_counters(), cpu.engine.read_counters())
+    s = gpu.generate_state()
+    assert sum(s['all_detected']) == ipc['confirmed_cases'] and sum(s['in_icu']) <= ipc['in_icu']
+    _assert_state_equal(gpu, cpu)
+    hg, hc = gpu.run(60), cpu.run(60)
+    assert np.array_equal(hg, hc)
+    _assert_state_equal(gpu, cpu)
