@@ -84,13 +84,9 @@ struct reina_engine {
     Tables h_tables;
     bool testing_ever = false;
     int uniform_meta = 0;
-    // independent kernels of a day run side by side on a second stream
-    hipStream_t s2 = nullptr;
-    hipEvent_t ev_fork1 = nullptr, ev_join1 = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
-    bool join2_pending = false;
-    // measured on MI355X / ROCm 7.2: cross-stream event waits cost more than the overlap wins back
-    // (HUS 0.108 -> 0.127 ms/day, 50 M agents 0.315 -> 0.311), so the second stream stays off
-    bool overlap = false;
+    // (running independent kernels of a day on a second stream was measured on MI355X / ROCm 7.2:
+    // the cross-stream event waits cost more than the overlap wins back -- HUS 0.108 -> 0.127 ms/day,
+    // 50 M agents 0.315 -> 0.311 -- so independent phases share ONE launch instead: k_hosp_contacts)
     // profiling
     bool profile = false;
     uint32_t profile_stride = 1;  // time the scan launch of every profile_stride-th day
@@ -443,7 +439,7 @@ __device__ void pro_vaccinate(const DevParams *P, const reina_buffers_t &B, cons
     }
 }
 
-__global__ __launch_bounds__(PRO_THREADS) void k_prologue(const MemberRef *M_, reina_day_t dp, int do_post, uint32_t hist_slot) {
+__global__ __launch_bounds__(PRO_THREADS) void k_prologue(const MemberRef *M_, reina_day_t dp, uint32_t hist_slot) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
@@ -499,32 +495,9 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const MemberRef *M_, r
         // HealthcareSystem.iterate: ct_cases_per_day = len(queue) (main.pyx:518-519)
         B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] = B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
     }
-    // weekly imports: here, or (two-stream mode) in k_imports_post beside the test-queue kernels;
-    // vaccination follows the test-queue pass in the reference (main.pyx:547-558) and is launched
-    // from k_vaccinate after both.
-    if (do_post) {
-        __syncthreads();
-        pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
-    }
-}
-
-// Population.infect_people_daily (main.pyx:1671-1685): imports that run after init_day's zeroing
-__global__ __launch_bounds__(PRO_THREADS) void k_imports_post(const MemberRef *M_, reina_day_t dp,
-                                                              uint32_t import_base) {
-    const MemberRef &mref_ = M_[blockIdx.y];
-    const DevParams *P = mref_.P;
-    const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
-    __shared__ uint8_t placed[PRO_MAX_IMPORTS];
-    __shared__ uint32_t s_unplaced;
-    __shared__ uint32_t s_import_base;
-    __shared__ int32_t new_by_age[REINA_MAX_AGES];
-    __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
-    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
-    const int tid = threadIdx.x;
-    if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
-    if (tid < REINA_MAX_AGES) new_by_age[tid] = 0;
-    if (tid < REINA_MAX_VARIANTS) new_by_variant[tid] = 0;
-    if (tid == 0) s_import_base = import_base;
+    // weekly imports (Population.infect_people_daily, main.pyx:1671-1685) run after init_day's
+    // zeroing; vaccination follows the test-queue pass in the reference (main.pyx:547-558) and is
+    // launched from k_vaccinate after both.
     __syncthreads();
     pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
 }
@@ -942,8 +915,8 @@ __device__ __forceinline__ SatFn icu_fn(int type) {
 enum { HL_INFECTED = 0, HL_DETECTED, HL_ALL_DETECTED, HL_HOSPITALIZED, HL_IN_WARD, HL_IN_ICU, HL_CUM_ICU,
        HL_DEAD, HL_NHD, HL_RECOVERED, HL_NR };
 
-__global__ __launch_bounds__(HOSP_THREADS) void k_hospital(const MemberRef *M_, reina_day_t dp,
-                                                           uint32_t scan_waves, uint32_t scan_tiles) {
+__device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_day_t &dp,
+                                               uint32_t scan_waves, uint32_t scan_tiles) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
@@ -1410,8 +1383,8 @@ static size_t con_shared_bytes(uint32_t nr_ages, uint32_t n_shards) {
     return sizeof(ConShared) + (size_t)nr_ages * REINA_MAX_ENTRIES * 4 + (n_shards > 1 ? REINA_PRESSURE_WORDS * 4 : 0);
 }
 
-__global__ __launch_bounds__(CON_THREADS) void k_contacts(const MemberRef *M_, reina_day_t dp,
-                                                          uint32_t scan_waves, uint32_t scan_tiles, int uniform_meta) {
+__device__ __forceinline__ void contacts_block(const MemberRef *M_, const reina_day_t &dp, uint32_t scan_waves,
+                                               uint32_t scan_tiles, int uniform_meta, uint32_t bx, uint32_t nbx) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
@@ -1421,7 +1394,7 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const MemberRef *M_, r
     uint32_t (*S_thr)[REINA_MAX_ENTRIES] = reinterpret_cast<uint32_t (*)[REINA_MAX_ENTRIES]>(smem_raw + sizeof(ConShared));
     int32_t *S_pressure = reinterpret_cast<int32_t *>(smem_raw + sizeof(ConShared) + (size_t)P->nr_ages * REINA_MAX_ENTRIES * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (blockIdx.x * CON_WAVES >= scan_waves) return;  // no slice for this workgroup
+    if (bx * CON_WAVES >= scan_waves) return;  // no slice for this workgroup
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&T->thr[0][0]);
         uint4 *dst = reinterpret_cast<uint4 *>(&S_thr[0][0]);
@@ -1444,9 +1417,9 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const MemberRef *M_, r
     const reina_disease_t &d = P->dis;
     const uint32_t n_shards = P->n_shards, shard_rank = P->shard_rank;
     const uint2 *items = reinterpret_cast<const uint2 *>(B.work_items);
-    const uint32_t total_waves = gridDim.x * CON_WAVES;
+    const uint32_t total_waves = nbx * CON_WAVES;
     uint32_t wave_contacts = 0;
-    for (uint32_t sw = blockIdx.x * CON_WAVES + wave; sw < scan_waves; sw += total_waves) {
+    for (uint32_t sw = bx * CON_WAVES + wave; sw < scan_waves; sw += total_waves) {
         const uint32_t slice_base = scan_slice_base(sw, scan_waves, scan_tiles);
         // successful attempts of this slice's sources go to the slice's own candidate region
         const uint32_t slice_cap = (sw + 1 < scan_waves ? scan_slice_base(sw + 1, scan_waves, scan_tiles) : P->max_work_items) - slice_base;
@@ -1609,6 +1582,21 @@ __global__ __launch_bounds__(CON_THREADS) void k_contacts(const MemberRef *M_, r
     if (n_shards > 1)
         for (int k = tid; k < REINA_PRESSURE_WORDS; k += CON_THREADS)
             if (S_pressure[k]) atomicAdd(&B.pressure[k], S_pressure[k]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hosp_contacts: the day's bed / ICU events and its contact sampling are independent (the events
+// rewrite hot words of agents leaving ILLNESS / HOSPITALIZED / IN_ICU and the bed counters; contacts
+// read the scan's exposure records, the susceptible bitmap and the claim words), so they share one
+// launch: workgroup 0 walks the events while workgroups 1.. sample contacts.  Both are 1024 threads;
+// VGPR use already limits either to one workgroup per CU, so the larger LDS request costs nothing.
+static_assert(HOSP_THREADS == CON_THREADS, "fused launch");
+__global__ __launch_bounds__(CON_THREADS) void k_hosp_contacts(const MemberRef *M_, reina_day_t dp, uint32_t scan_waves,
+                                                               uint32_t scan_tiles, int uniform_meta) {
+    if (blockIdx.x == 0)
+        hospital_block(M_, dp, scan_waves, scan_tiles);
+    else
+        contacts_block(M_, dp, scan_waves, scan_tiles, uniform_meta, blockIdx.x - 1, gridDim.x - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1971,15 +1959,12 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK(hipMalloc(&e->d_ref, sizeof(MemberRef)));
     HIP_CHECK(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice));
-    HIP_CHECK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork1, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&e->ev_join1, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)con_shared_bytes(REINA_MAX_AGES, REINA_MAX_SHARDS)));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hospital), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(REINA_MAX_HOSP_EVENTS * 8)));
+    {
+        size_t lds = con_shared_bytes(REINA_MAX_AGES, REINA_MAX_SHARDS);
+        if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_contacts),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     *out = e;
     return REINA_OK;
 }
@@ -1987,14 +1972,6 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
 int reina_destroy(reina_engine_t *e) {
     if (!e) return REINA_E_INVALID;
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
-    if (e->s2) {
-        hipStreamSynchronize(e->s2);
-        hipStreamDestroy(e->s2);
-        hipEventDestroy(e->ev_fork1);
-        hipEventDestroy(e->ev_join1);
-        hipEventDestroy(e->ev_fork2);
-        hipEventDestroy(e->ev_join2);
-    }
     hipFree(e->d_params);
     hipFree(e->d_tables);
     hipFree(e->d_ref);
@@ -2067,30 +2044,17 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
 static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp,
                             uint32_t hist_slot, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
-    hipLaunchKernelGGL(k_prologue, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, e->overlap ? 0 : 1, hist_slot);
+    hipLaunchKernelGGL(k_prologue, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);
     if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
-    uint32_t n_pre = 0, n_post = 0;
-    for (uint32_t b = 0; b < dp.n_import_batches; b++)
-        (dp.import_batches[b].pre_init ? n_pre : n_post) += dp.import_batches[b].count;
-    hipStream_t s2 = e->overlap ? e->s2 : s;
     if (e->testing_ever) {
-        // test queue + tracing touch only infected / removed agents and the detection counters;
-        // weekly imports touch only never-infected agents: they may run side by side
-        if (e->overlap) {
-            HIP_CHECK(hipEventRecord(e->ev_fork1, s));
-            HIP_CHECK(hipStreamWaitEvent(s2, e->ev_fork1, 0));
-        }
         const int g = grid_for(N / 64 + 1, 256, 256);
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            hipLaunchKernelGGL(k_test_trace<0>, dim3(g, K), dim3(256), 0, s2, refs, dp);  // detects + traces
-            hipLaunchKernelGGL(k_test_trace<1>, dim3(g, K), dim3(256), 0, s2, refs, dp);
+            hipLaunchKernelGGL(k_test_trace<0>, dim3(g, K), dim3(256), 0, s, refs, dp);  // detects + traces
+            hipLaunchKernelGGL(k_test_trace<1>, dim3(g, K), dim3(256), 0, s, refs, dp);
         } else {
-            hipLaunchKernelGGL(k_test_detect, dim3(g, K), dim3(256), 0, s2, refs, dp);
+            hipLaunchKernelGGL(k_test_detect, dim3(g, K), dim3(256), 0, s, refs, dp);
         }
-        if (e->overlap) HIP_CHECK(hipEventRecord(e->ev_join1, s2));
     }
-    if (n_post && e->overlap) hipLaunchKernelGGL(k_imports_post, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, n_pre);
-    if (e->testing_ever && e->overlap) HIP_CHECK(hipStreamWaitEvent(s, e->ev_join1, 0));
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
     // scan geometry: tiles of 512 agents, as many waves as tiles (small populations) up to 8192
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
@@ -2107,21 +2071,13 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     } else {
         hipLaunchKernelGGL(k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, refs, dp);
     }
-    // bed / ICU events (one workgroup per member, latency-bound) may run beside the contact kernel
-    if (e->overlap) {
-        HIP_CHECK(hipEventRecord(e->ev_fork2, s));
-        HIP_CHECK(hipStreamWaitEvent(s2, e->ev_fork2, 0));
-    }
-    hipLaunchKernelGGL(k_hospital, dim3(1, K), dim3(HOSP_THREADS), REINA_MAX_HOSP_EVENTS * 8, s2, refs, dp, scan_waves, scan_tiles);
-    if (e->overlap) {
-        HIP_CHECK(hipEventRecord(e->ev_join2, s2));
-        e->join2_pending = true;
-    }
-    {
+    {   // bed / ICU events (workgroup 0, latency-bound) beside the contact sampling (workgroups 1..)
         uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
         if (con_blocks > 512) con_blocks = 512;
-        hipLaunchKernelGGL(k_contacts, dim3(con_blocks, K), dim3(CON_THREADS), con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards), s,
-                           refs, dp, scan_waves, scan_tiles, e->uniform_meta);
+        size_t lds = con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards);
+        if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
+        hipLaunchKernelGGL(k_hosp_contacts, dim3(con_blocks + 1, K), dim3(CON_THREADS), lds, s, refs, dp, scan_waves, scan_tiles,
+                           e->uniform_meta);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
@@ -2129,10 +2085,6 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
 
 static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
-    if (e->join2_pending) {  // installs read list flags the hospital kernel may clear: join first
-        HIP_CHECK(hipStreamWaitEvent(s, e->ev_join2, 0));
-        e->join2_pending = false;
-    }
     if (e->cfg.n_shards > 1)
         hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
     {
