@@ -915,6 +915,126 @@ __device__ __forceinline__ SatFn icu_fn(int type) {
 enum { HL_INFECTED = 0, HL_DETECTED, HL_ALL_DETECTED, HL_HOSPITALIZED, HL_IN_WARD, HL_IN_ICU, HL_CUM_ICU,
        HL_DEAD, HL_NHD, HL_RECOVERED, HL_NR };
 
+// Bitonic sort of n (power of two, <= E * 1024) 64-bit keys in LDS by the 1024-thread workgroup.
+// Thread t keeps elements t*E .. t*E+E-1 in registers: compare-exchange strides below E stay in
+// registers, strides below 64*E are wave shuffles, only the strides of 64*E and above go through
+// LDS (element r of thread t at [r][t], conflict-free) -- 10 LDS round trips for 16384 keys
+// instead of 105.
+template <int E, int STRD>
+__device__ __forceinline__ void hosp_sort_reg(uint64_t (&x)[E], int size, int tid) {
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        if ((r & STRD) == 0 && (r | STRD) < E) {
+            const bool up = (((tid * E) + r) & size) == 0;
+            const uint64_t a = x[r], b = x[r | STRD];
+            const bool sw = (a > b) == up;
+            x[r] = sw ? b : a;
+            x[r | STRD] = sw ? a : b;
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void hosp_sort(uint64_t *ev, int n, int tid) {
+    uint64_t x[E];
+    const int T = n / E > 0 ? n / E : 1;   // threads that hold keys; the others idle through the barriers
+    const bool active = tid < T;            // (events past n in the same LDS array must stay untouched)
+#pragma unroll
+    for (int r = 0; r < E; r++) x[r] = (tid * E + r < n) ? ev[tid * E + r] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int strd = size >> 1; strd > 0; strd >>= 1) {
+            if (strd >= 64 * E) {
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < E; r++) ev[r * T + tid] = x[r];
+                }
+                __syncthreads();
+                const int m = strd / E;
+                const bool take_min = ((tid & m) == 0) == (((tid * E) & size) == 0);
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < E; r++) {
+                        const uint64_t o = ev[r * T + (tid ^ m)];
+                        x[r] = take_min ? (o < x[r] ? o : x[r]) : (o > x[r] ? o : x[r]);
+                    }
+                }
+                __syncthreads();
+            } else if (strd >= E) {
+                const int m = strd / E;   // partner lane = lane ^ m, m in 1..32
+                const bool take_min = ((tid & m) == 0) == (((tid * E) & size) == 0);
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const uint64_t o = __shfl_xor((unsigned long long)x[r], m);
+                    x[r] = take_min ? (o < x[r] ? o : x[r]) : (o > x[r] ? o : x[r]);
+                }
+            } else {
+                switch (strd) {
+                    case 1: hosp_sort_reg<E, 1>(x, size, tid); break;
+                    case 2: hosp_sort_reg<E, 2>(x, size, tid); break;
+                    case 4: hosp_sort_reg<E, 4>(x, size, tid); break;
+                    default: hosp_sort_reg<E, 8>(x, size, tid); break;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < E; r++)
+        if (tid * E + r < n) ev[tid * E + r] = x[r];
+    __syncthreads();
+}
+
+// Larger event sets: one counting pass over the top 11 priority bits (2048 buckets, two per thread)
+// scatters the keys through a global scratch array, then every thread insertion-sorts its own two
+// adjacent buckets (16 keys on average for 16384 events) -- O(n) instead of a single-CU O(n log^2 n)
+// network.  `cnt` / `cur` are 2048 ints each (the SatFn arrays, not yet in use at this point).
+__device__ __forceinline__ void hosp_bucket_sort(uint64_t *ev, int R, int tid, uint64_t *scratch, int *cnt, int *cur,
+                                                 int (*s_wsum)[HOSP_THREADS / 64]) {
+    cnt[2 * tid] = 0;
+    cnt[2 * tid + 1] = 0;
+    __syncthreads();
+    for (int k = tid; k < R; k += HOSP_THREADS) atomicAdd(&cnt[(int)(ev[k] >> 43) & 2047], 1);
+    __syncthreads();
+    const int c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1], sum = c0 + c1;
+    const int lane = tid & 63, wv = tid >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wsum[0][wv] = inc;
+    __syncthreads();
+    int base0 = inc - sum;
+    for (int w2 = 0; w2 < wv; w2++) base0 += s_wsum[0][w2];
+    cur[2 * tid] = base0;
+    cur[2 * tid + 1] = base0 + c0;
+    __syncthreads();
+    for (int k = tid; k < R; k += HOSP_THREADS) {
+        const uint64_t e = ev[k];
+        scratch[atomicAdd(&cur[(int)(e >> 43) & 2047], 1)] = e;
+    }
+    __syncthreads();
+    for (int k = tid; k < R; k += HOSP_THREADS) ev[k] = ld_claim(&scratch[k]);
+    __syncthreads();
+    for (int i = base0 + 1; i < base0 + sum; i++) {
+        const uint64_t key = ev[i];
+        int j = i - 1;
+        while (j >= base0 && ev[j] > key) {
+            ev[j + 1] = ev[j];
+            j--;
+        }
+        ev[j + 1] = key;
+    }
+    __syncthreads();
+}
+
+#ifdef REINA_HOSP_STAMPS
+// diagnostic: per-phase time of the event walk accumulated in buffers.mirror[0..7] (100 MHz ticks)
+#define HSTAMP(k) do { if (threadIdx.x == 0) { uint64_t t_ = wall_clock64(); atomicAdd((unsigned long long *)&B.mirror[k], (unsigned long long)(t_ - hs_t)); hs_t = t_; } } while (0)
+#else
+#define HSTAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_day_t &dp,
                                                uint32_t scan_waves, uint32_t scan_tiles) {
     const MemberRef &mref_ = M_[blockIdx.y];
@@ -922,6 +1042,9 @@ __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *ev = reinterpret_cast<uint64_t *>(smem);               // [M2]
+#ifdef REINA_HOSP_STAMPS
+    uint64_t hs_t = wall_clock64();
+#endif
     __shared__ int s_b, s_c;
     __shared__ SatFn s_fb[HOSP_THREADS], s_fc[HOSP_THREADS];
     __shared__ int32_t s_cnt[HL_NR][REINA_MAX_AGES];
@@ -979,6 +1102,7 @@ __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_
             if (tid == 0) s_tot[ty] = total;
         }
         __syncthreads();
+    HSTAMP(1);
     }
     const int nH = s_tot[EV_HOSPITALIZE], nT = s_tot[EV_TO_ICU], nW = s_tot[EV_RELEASE_WARD], nI = s_tot[EV_RELEASE_ICU];
     int M = nH + nT + nW + nI;
@@ -1023,30 +1147,21 @@ __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_
         }
     }
     __syncthreads();
+    HSTAMP(2);
     if (ordered) {
-        // sort the prefix [0, M2): entries past R (other types, or past M) compare as +infinity
-        for (int k = tid; k < M2; k += HOSP_THREADS)
-            if (k >= R && k < M) ev[k] |= 1ull << 62;
-        for (int k = M + tid; k < M2; k += HOSP_THREADS) ev[k] = ~0ull;
-        __syncthreads();
-        for (int size = 2; size <= M2; size <<= 1) {
-            for (int strd = size >> 1; strd > 0; strd >>= 1) {
-                for (int k = tid; k < M2; k += HOSP_THREADS) {
-                    int partner = k ^ strd;
-                    if (partner > k) {
-                        bool up = (k & size) == 0;
-                        uint64_t a = ev[k], b = ev[partner];
-                        if ((a > b) == up) {
-                            ev[k] = b;
-                            ev[partner] = a;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
+        if (M2 <= HOSP_THREADS) {
+            // sort the prefix [0, M2): entries past R (other types, or past M) compare as +infinity
+            for (int k = tid; k < M2; k += HOSP_THREADS)
+                if (k >= R && k < M) ev[k] |= 1ull << 62;
+            for (int k = M + tid; k < M2; k += HOSP_THREADS) ev[k] = ~0ull;
+            __syncthreads();
+            hosp_sort<1>(ev, M2, tid);
+            for (int k = tid; k < M2 && k < M; k += HOSP_THREADS) ev[k] &= ~(1ull << 62);
+            __syncthreads();
+        } else {
+            hosp_bucket_sort(ev, R, tid, B.hosp_events, reinterpret_cast<int *>(s_fb), reinterpret_cast<int *>(s_fc), s_wsum);
         }
-        for (int k = tid; k < M2 && k < M; k += HOSP_THREADS) ev[k] &= ~(1ull << 62);
-        __syncthreads();
+    HSTAMP(3);
         // chunked scan: thread t owns events [t*per, (t+1)*per)
         const int per = (R + HOSP_THREADS - 1) / HOSP_THREADS;
         const int lo = min(R, tid * per), hi = min(R, lo + per);
@@ -1121,6 +1236,7 @@ __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_
         if (dc) atomicAdd(&s_c, dc);
     }
     __syncthreads();
+    HSTAMP(4);
     const reina_disease_t &d = P->dis;
     for (int k = tid; k < M; k += HOSP_THREADS) {
         uint64_t e = ev[k];
@@ -1184,6 +1300,7 @@ __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_
         B.hot[i] = w;
     }
     __syncthreads();
+    HSTAMP(5);
     for (int k = tid; k < HL_NR * REINA_MAX_AGES; k += HOSP_THREADS) {
         int32_t v = (&s_cnt[0][0])[k];
         if (v) {
@@ -1197,6 +1314,7 @@ __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_
         B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] = s_b;
         B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] = s_c;
     }
+    HSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------

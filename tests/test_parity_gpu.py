@@ -318,3 +318,19 @@ def test_initial_population_condition(beds, icu, n, ipc):
     hg, hc = gpu.run(60), cpu.run(60)
     assert np.array_equal(hg, hc)
     _assert_state_equal(gpu, cpu)
+
+
+def test_large_bed_event_sets():
+    """An unmitigated wave in 2.5 M agents with few beds: thousands of bed / ICU events per day
+    while capacity binds, i.e. the counting-sort path of the event walk (more than 1024 ordered
+    events) -- per-day counters and final state bit-exact vs oracle B."""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=900, icu_units=60)
+    ivs = [['import-infections', '2020-02-19', 3000], ['import-infections', '2020-02-25', 3000, 'b1.1.7'],
+           ['test-all-with-symptoms', '2020-02-20']]
+    ages = datasets.scaled_population(2_500_000)
+    gpu, cpu = _run_and_compare(v, ages, 3, 75, interventions=ivs, chunk=25)
+    s = gpu.generate_state()
+    assert s['available_hospital_beds'] == 0 and s['available_icu_units'] == 0
+    c = gpu.per_age_counters()
+    assert c['all_infected'].sum() > 1_000_000   # the wave is big enough for > 1024 events a day
