@@ -19,6 +19,7 @@ Extra objects on the line:
                from HIP events recorded on the launch stream inside the timed region (every --time-every-th day), vs 8 TB/s.
   cpu_baseline the sequential C oracle (oracle/reina_seq.c, bit-exact vs the reference cythonsim)
                timed on one host core on a bounded sample (first days of the same workload).
+  ensemble     BASELINE config 5 shape: 32 seeds of the HUS scenario as one engine group.
   large        the same measurement on BASELINE configs[2] (synthetic 50 M agents, HUS age shape,
                beds/ICU/imports scaled) -- the HBM-resident regime the roofline is meant for.
 """
@@ -138,6 +139,69 @@ def cpu_baseline(variables, ages, seed, days):
                        'HUS %d agents, first %d days of the default scenario, 1 thread, %.1f s' % (n, days, dt))
 
 
+_CPU_WORKER = r"""
+import copy, sys, time
+sys.path.insert(0, %(root)r)
+from oracle import seq_oracle
+from reina_model_amd import datasets
+from reina_model_amd.variables import VARIABLE_DEFAULTS
+ages = datasets.get_population_for_area()
+ctx = seq_oracle.make_context(copy.deepcopy(VARIABLE_DEFAULTS), ages, %(seed)d)
+while time.time() < %(start)f:
+    time.sleep(0.01)
+t0 = time.time()
+for _ in range(%(days)d):
+    ctx.iterate()
+print(t0, time.time())
+"""
+
+
+def cpu_baseline_all_cores(days, max_procs=64):
+    """The reference's Monte-Carlo shape (calc/simulation.py:376: a pool of processes, one
+    simulation each) with the sequential C restatement: one HUS simulation per host core, all
+    started together.  Child processes are spawned BEFORE this process touches the GPU."""
+    import subprocess
+    procs = min(os.cpu_count() or 1, max_procs)
+    start = time.time() + 12.0
+    ps = [subprocess.Popen([sys.executable, '-c', _CPU_WORKER % dict(root=ROOT, seed=1000 + k, start=start, days=days)],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(procs)]
+    spans = []
+    for p in ps:
+        out, _ = p.communicate(timeout=600)
+        if p.returncode == 0:
+            a, b = out.decode().split()[-2:]
+            spans.append((float(a), float(b)))
+    if not spans:
+        return None
+    wall = max(b for _, b in spans) - min(a for a, _ in spans)
+    n = 1685983
+    return dict(value=round(n * days * len(spans) / wall, 1), unit='agent-days/s', cores=len(spans), kind='port',
+                sample='%d concurrent sequential simulations (one per core, cores capped at %d), HUS %d agents, '
+                       'first %d days each, %.1f s wall' % (len(spans), max_procs, n, days, wall))
+
+
+def ensemble_line(seeds, days, device):
+    """BASELINE config 5 shape: a Monte-Carlo ensemble of HUS simulations on one GPU, stepped as an
+    engine group (one launch per phase for all members)."""
+    import torch
+    from reina_model_amd import datasets, ensemble, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ages = datasets.get_population_for_area()
+    planner = simulation.make_context(v, age_counts=ages, seed=0, device=device)
+    plan = planner.make_plan(days)
+    members = [simulation.make_context(v, age_counts=ages, seed=100 + k, device=device) for k in range(seeds)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ensemble.run_group_plan(members, plan)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = int(ages.sum())
+    return dict(workload='%d seeds x HUS %d agents x %d days, one engine group' % (seeds, n, days),
+                value=round(seeds * n * days / dt, 1), unit='agent-days/s', ms_per_step=round(dt * 1000 / days, 6),
+                members=seeds)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -148,12 +212,20 @@ def main():
     ap.add_argument('--cpu-days', type=int, default=120)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-large', action='store_true')
+    ap.add_argument('--no-ensemble', action='store_true')
+    ap.add_argument('--ensemble-seeds', type=int, default=32)
+    ap.add_argument('--cpu-all-cores-days', type=int, default=120)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--time-every', type=int, default=8,
                     help='k_scan launches carry HIP event timestamps on every k-th day of the timed region')
     ap.add_argument('--preheat-days', type=int, default=200,
                     help='days of a throw-away simulation run before the measured one (GPU clocks, one-time costs)')
     a = ap.parse_args()
+
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    cpu_all = None
+    if world_env == 1 and not a.no_cpu and not a.agents and a.cpu_all_cores_days > 0:
+        cpu_all = cpu_baseline_all_cores(a.cpu_all_cores_days)   # before anything initialises the GPU
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
@@ -221,10 +293,14 @@ def main():
                 'roofline': roofline_obj(nl, a.steps, profl, statsl, a.time_every),
                 'final_all_infected': statsl['final_all_infected'],
             }
+        if not a.no_ensemble and world == 1 and not a.agents:
+            out['ensemble'] = ensemble_line(a.ensemble_seeds, a.steps, device)
         if not a.no_cpu:
             hus = datasets.get_population_for_area()
             out['cpu_baseline'] = cpu_baseline(copy.deepcopy(VARIABLE_DEFAULTS), hus, a.seed, a.cpu_days)
             out['cpu_baseline']['cores_available'] = os.cpu_count()
+            if cpu_all is not None:
+                out['cpu_baseline']['all_cores'] = cpu_all
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -2191,7 +2191,7 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     }
     {   // bed / ICU events (workgroup 0, latency-bound) beside the contact sampling (workgroups 1..)
         uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
-        if (con_blocks > 512) con_blocks = 512;
+        if (con_blocks > 255) con_blocks = 255;  // with the event workgroup: one resident wave of workgroups on 256 CUs
         size_t lds = con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards);
         if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
         hipLaunchKernelGGL(k_hosp_contacts, dim3(con_blocks + 1, K), dim3(CON_THREADS), lds, s, refs, dp, scan_waves, scan_tiles,
