@@ -49,6 +49,7 @@ extern "C" {
 #define REINA_PROBLEM_QUEUE_OVERFLOW 102
 #define REINA_PROBLEM_HOSPITAL_OVERFLOW 103
 #define REINA_PROBLEM_DAYS_OVERFLOW 104
+#define REINA_PROBLEM_SYNC_TIMEOUT 105   /* a workgroup waited > 20 ms for the day's opening bookkeeping */
 
 /* per-age counter arrays, Population stats main.pyx:1335-1341 */
 enum {
@@ -75,6 +76,7 @@ enum {
 enum {
     REINA_L_WORK = 0, REINA_L_CAND, REINA_L_QUEUE0, REINA_L_QUEUE1, REINA_L_LEVEL1, REINA_L_HOSP,
     REINA_L_CONTACTS, REINA_L_HOSP_ADMIT, REINA_L_ICU_ADMIT,
+    REINA_L_DAY_OPEN,                                   /* day + 1 once that day's snapshot / zeroing is done */
     REINA_L_VACC_CURSOR = 16,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_NR = 32
 };

@@ -439,7 +439,7 @@ __device__ void pro_vaccinate(const DevParams *P, const reina_buffers_t &B, cons
     }
 }
 
-__global__ __launch_bounds__(PRO_THREADS) void k_prologue(const MemberRef *M_, reina_day_t dp, uint32_t hist_slot) {
+__device__ __forceinline__ void prologue_block(const MemberRef *M_, const reina_day_t &dp, uint32_t hist_slot) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
@@ -491,10 +491,14 @@ __global__ __launch_bounds__(PRO_THREADS) void k_prologue(const MemberRef *M_, r
         B.control[REINA_L_CONTACTS] = 0;
         B.control[REINA_L_HOSP_ADMIT] = 0;
         B.control[REINA_L_ICU_ADMIT] = 0;
-        B.control[REINA_L_LEVEL1] = 0;
         // HealthcareSystem.iterate: ct_cases_per_day = len(queue) (main.pyx:518-519)
         B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] = B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
     }
+    // the day is open: the test-queue workgroups of the same launch (k_open) may start; what follows
+    // (weekly imports) only touches never-infected agents and the infection counters
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&B.control[REINA_L_DAY_OPEN], (int32_t)dp.day + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     // weekly imports (Population.infect_people_daily, main.pyx:1671-1685) run after init_day's
     // zeroing; vaccination follows the test-queue pass in the reference (main.pyx:547-558) and is
     // launched from k_vaccinate after both.
@@ -524,28 +528,49 @@ __device__ __forceinline__ void queue_append(const DevParams *P, const reina_buf
     (which ? B.queue1 : B.queue0)[pos] = idx;
 }
 
+// Test-queue workgroups share the launch of the day's opening workgroup (k_open): before they add
+// to the detection counters they wait here until it has taken the history snapshot and zeroed the
+// daily counters.  The wait
+// is one-directional (on a workgroup with a lower index of the same launch, which the dispatcher
+// starts first), and bounded: after 20 ms the day is flagged failed instead of hanging the device.
+__device__ __forceinline__ void wait_day_open(const reina_buffers_t &B, uint32_t day) {
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = wall_clock64();
+        while (__hip_atomic_load(&B.control[REINA_L_DAY_OPEN], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (int32_t)day + 1) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 2000000ull) {  // 100 MHz ticks
+                set_problem(B.counters, REINA_PROBLEM_SYNC_TIMEOUT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // Q1: every queued test is positive (quirk Q8): clear QUEUED, set DETECTED
-__global__ __launch_bounds__(256) void k_test_detect(const MemberRef *M_, reina_day_t dp) {
+__device__ __forceinline__ void test_detect_block(const MemberRef *M_, const reina_day_t &dp, uint32_t bx, uint32_t nbx) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     __shared__ int32_t s_det[REINA_MAX_AGES];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
-    if (B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] <= (int)(blockIdx.x * blockDim.x)) return;
+    if (B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] <= (int)(bx * blockDim.x)) return;
     if (threadIdx.x <= REINA_MAX_AGES) s_age_start[threadIdx.x] = P->age_start[threadIdx.x];
     if (threadIdx.x < REINA_MAX_AGES) s_det[threadIdx.x] = 0;
     __syncthreads();
     const int cur = dp.day & 1;
     const uint32_t *q = cur ? B.queue1 : B.queue0;
     const int n = B.control[cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    for (int k = bx * blockDim.x + threadIdx.x; k < n; k += nbx * blockDim.x) {
         uint32_t i = q[k];
         uint32_t w = B.hot[i];
         if (w & RH_DETECTED) set_problem(B.counters, 7 /* WRONG_STATE */);
         B.hot[i] = (w & ~RH_QUEUED) | RH_DETECTED;
         atomicAdd(&s_det[age_of(s_age_start, i, 0, (int)P->nr_ages - 1)], 1);
     }
-    __syncthreads();
+    // hot words, queues and lists are free to touch from the first instruction of the launch; the
+    // detection COUNTERS wait for the opening workgroup's snapshot + daily zeroing (normally long done)
+    wait_day_open(B, dp.day);
     if (threadIdx.x < REINA_MAX_AGES && s_det[threadIdx.x]) {
         atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
         atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
@@ -569,7 +594,7 @@ __device__ __forceinline__ bool try_queue(const DevParams *P, const reina_buffer
 // every member of today's queue carries QUEUED until its single store replaces it with DETECTED,
 // so a tracer can never re-queue another member, whichever of the two runs first.
 template <int LEVEL>
-__global__ __launch_bounds__(256) void k_test_trace(const MemberRef *M_, reina_day_t dp) {
+__device__ __forceinline__ void test_trace_block(const MemberRef *M_, const reina_day_t &dp, uint32_t bx, uint32_t nbx) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
@@ -578,13 +603,13 @@ __global__ __launch_bounds__(256) void k_test_trace(const MemberRef *M_, reina_d
     const int cur = dp.day & 1, nxt = cur ^ 1;
     const uint32_t *src = LEVEL == 0 ? (cur ? B.queue1 : B.queue0) : B.level1;
     const int n = LEVEL == 0 ? B.control[cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0] : B.control[REINA_L_LEVEL1];
-    if (n <= (int)(blockIdx.x * blockDim.x)) return;
+    if (n <= (int)(bx * blockDim.x)) return;
     if (LEVEL == 0) {
         if (threadIdx.x <= REINA_MAX_AGES) s_age_start[threadIdx.x] = P->age_start[threadIdx.x];
         if (threadIdx.x < REINA_MAX_AGES) s_det[threadIdx.x] = 0;
         __syncthreads();
     }
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    for (int k = bx * blockDim.x + threadIdx.x; k < n; k += nbx * blockDim.x) {
         uint32_t i = src[k];
         uint32_t wi;
         if (LEVEL == 0) {
@@ -617,11 +642,32 @@ __global__ __launch_bounds__(256) void k_test_trace(const MemberRef *M_, reina_d
         }
     }
     if (LEVEL == 0) {
-        __syncthreads();
+        wait_day_open(B, dp.day);   // (includes the workgroup barrier) counters only after the snapshot + zeroing
         if (threadIdx.x < REINA_MAX_AGES && s_det[threadIdx.x]) {
             atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
             atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_test_trace1(const MemberRef *M_, reina_day_t dp) {
+    test_trace_block<1>(M_, dp, blockIdx.x, gridDim.x);
+}
+
+// k_open: the first launch of a day.  Workgroup 0 opens the day (prologue_block: snapshot, beds,
+// intervention imports, daily zeroing, then the weekly imports); workgroups 1.. work off the test
+// queue (MODE 1: detection only, MODE 2: detection + level-0 contact tracing) as soon as workgroup 0
+// signals that the bookkeeping part is done -- the import placement that follows it touches only
+// never-infected agents and infection counters, the test queue only infected agents and detection
+// counters, so the two run side by side inside one launch.
+template <int MODE>
+__global__ __launch_bounds__(PRO_THREADS) void k_open(const MemberRef *M_, reina_day_t dp, uint32_t hist_slot) {
+    if (blockIdx.x == 0) {
+        prologue_block(M_, dp, hist_slot);
+    } else if (MODE == 1) {
+        test_detect_block(M_, dp, blockIdx.x - 1, gridDim.x - 1);
+    } else if (MODE == 2) {
+        test_trace_block<0>(M_, dp, blockIdx.x - 1, gridDim.x - 1);
     }
 }
 
@@ -1968,7 +2014,10 @@ __global__ __launch_bounds__(256) void k_install(const MemberRef *M_, reina_day_
         if (s_infectors) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTORS)], s_infectors);
         if (s_infections) atomicAdd(&B.counters[SC_IDX(REINA_S_TOTAL_INFECTIONS)], s_infections);
         // today's test queue has been processed (k_test_*): empty it for the day after tomorrow
-        if (blockIdx.x == 0) B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] = 0;
+        if (blockIdx.x == 0) {
+            B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0] = 0;
+            B.control[REINA_L_LEVEL1] = 0;   // consumed by k_test_trace1; tomorrow's level-0 pass appends from its first instruction
+        }
     }
 }
 
@@ -2162,15 +2211,16 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
 static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp,
                             uint32_t hist_slot, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
-    hipLaunchKernelGGL(k_prologue, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);
     if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
-    if (e->testing_ever) {
-        const int g = grid_for(N / 64 + 1, 256, 256);
+    if (!e->testing_ever) {
+        hipLaunchKernelGGL(k_open<0>, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);
+    } else {
+        const int g = 1 + grid_for(N / 64 + 1, PRO_THREADS, 64);
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            hipLaunchKernelGGL(k_test_trace<0>, dim3(g, K), dim3(256), 0, s, refs, dp);  // detects + traces
-            hipLaunchKernelGGL(k_test_trace<1>, dim3(g, K), dim3(256), 0, s, refs, dp);
+            hipLaunchKernelGGL(k_open<2>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);  // detects + traces
+            hipLaunchKernelGGL(k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
         } else {
-            hipLaunchKernelGGL(k_test_detect, dim3(g, K), dim3(256), 0, s, refs, dp);
+            hipLaunchKernelGGL(k_open<1>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);
         }
     }
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);

@@ -42,7 +42,7 @@ PROBLEM_TO_STR = {
     3: 'Hospital accounting failure', 4: 'Negative number of contacts', 5: 'Malloc failure',
     6: 'Other failure', 7: 'Wrong state', 8: 'Contact probability failure', 9: 'Infectees mismatch',
     100: 'Work list overflow', 101: 'Candidate list overflow', 102: 'Testing queue overflow',
-    103: 'Hospital event list overflow', 104: 'Day counter overflow',
+    103: 'Hospital event list overflow', 104: 'Day counter overflow', 105: 'Device synchronisation timeout',
 }
 # main.pyx:660-682: infectiousness by day relative to symptom onset (Luca et al. 2020)
 INFECTIOUSNESS_OVER_TIME = (
