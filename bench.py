@@ -56,17 +56,20 @@ def scaled_scenario(variables, total_agents):
     return v, datasets.scaled_population(total_agents)
 
 
-def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=1):
+def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=1, preheat_runs=3):
     import numpy as np
     import torch
     from reina_model_amd import engine as eng
     from reina_model_amd import sharding, simulation
     comm = sharding.TorchComm() if dist is not None else None
-    if preheat:
-        # throw-away run of the same workload (untimed, separate state): brings the GPU out of its
-        # idle power state and pays one-time runtime costs (first timestamped dispatches, staging
-        # buffers of the table uploads, allocator pools) before the measured simulation exists
-        pre = simulation.make_context(variables, age_counts=ages, seed=seed + 1000003, device=device, comm=comm)
+    for rep in range(preheat_runs if preheat else 0):
+        # throw-away runs of the same workload (untimed, separate state): bring the GPU out of its
+        # idle power state and pay one-time runtime costs before the measured simulation exists.
+        # Measured on ROCm 7.2 (tools/bench_debug.py): each of the first two or three full runs of a
+        # process that carry timestamped dispatches stalls ~7 ms inside ONE of its table uploads (a
+        # runtime-internal pool growing while the host is >1000 dispatches ahead); later runs never
+        # do -- hence three preheat runs, profiled exactly like the timed one.
+        pre = simulation.make_context(variables, age_counts=ages, seed=seed + 1000003 + rep, device=device, comm=comm)
         pre.engine.profile_enable(stride)
         pre.run(preheat, record_history=True)
         pre.synchronize()
@@ -218,7 +221,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--time-every', type=int, default=8,
                     help='k_scan launches carry HIP event timestamps on every k-th day of the timed region')
-    ap.add_argument('--preheat-days', type=int, default=200,
+    ap.add_argument('--preheat-days', type=int, default=365,
                     help='days of a throw-away simulation run before the measured one (GPU clocks, one-time costs)')
     a = ap.parse_args()
 
@@ -285,7 +288,7 @@ def main():
                 pass
         if not a.no_large and world == 1 and not a.agents:
             vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.large_agents)
-            dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, preheat=min(a.preheat_days, 60), stride=a.time_every)
+            dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, preheat=min(a.preheat_days, 120), stride=a.time_every)
             out['large'] = {
                 'workload': 'synthetic %d agents (BASELINE configs[2]), default scenario scaled, %d days' % (nl, a.steps),
                 'value': round(nl * a.steps / dtl, 1), 'unit': 'agent-days/s',

@@ -77,6 +77,7 @@ enum {
     REINA_L_WORK = 0, REINA_L_CAND, REINA_L_QUEUE0, REINA_L_QUEUE1, REINA_L_LEVEL1, REINA_L_HOSP,
     REINA_L_CONTACTS, REINA_L_HOSP_ADMIT, REINA_L_ICU_ADMIT,
     REINA_L_DAY_OPEN,                                   /* day + 1 once that day's snapshot / zeroing is done */
+    REINA_L_TRACE_DONE,                                 /* level-0 tracing workgroups finished today (folded level 1) */
     REINA_L_VACC_CURSOR = 16,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_NR = 32
 };

@@ -82,6 +82,14 @@ struct reina_engine {
     MemberRef *d_ref = nullptr;   // {d_params, d_tables, buf, no history base} for single-engine launches
     DevParams h_params;
     Tables h_tables;
+    // pinned staging ring for table uploads: the copies are queued behind the days already issued
+    // without stalling the host (a pageable source would drain the stream first)
+    // (a slot is reused once its copy has left it; while the host runs far ahead of the GPU new
+    // slots are added instead of waiting, up to MAX_STAGES)
+    struct Stage { DevParams p; Tables t; };
+    static constexpr size_t MAX_STAGES = 32;
+    std::vector<Stage *> stage;           // hipHostMalloc'd, one per slot
+    std::vector<hipEvent_t> stage_ev;
     bool testing_ever = false;
     int uniform_meta = 0;
     // (running independent kernels of a day on a second stream was measured on MI355X / ROCm 7.2:
@@ -593,7 +601,7 @@ __device__ __forceinline__ bool try_queue(const DevParams *P, const reina_buffer
 // Level 0 also performs the detection of its queue entry (k_test_detect's job) in the same pass:
 // every member of today's queue carries QUEUED until its single store replaces it with DETECTED,
 // so a tracer can never re-queue another member, whichever of the two runs first.
-template <int LEVEL>
+template <int LEVEL, bool FOLD = false>
 __device__ __forceinline__ void test_trace_block(const MemberRef *M_, const reina_day_t &dp, uint32_t bx, uint32_t nbx) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
@@ -648,6 +656,25 @@ __device__ __forceinline__ void test_trace_block(const MemberRef *M_, const rein
             atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
         }
     }
+    if (LEVEL == 0 && FOLD) {
+        // small populations: the level-0 workgroup that finishes last walks the level-1 list itself
+        // (a few hundred entries) instead of a launch of its own
+        __shared__ int s_last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t busy = ((uint32_t)n + blockDim.x - 1) / blockDim.x;   // workgroups that had queue entries
+            if (busy > nbx) busy = nbx;
+            const int done = atomicAdd(&B.control[REINA_L_TRACE_DONE], 1) + 1;
+            s_last = done == (int)busy;
+            if (s_last) {
+                B.control[REINA_L_TRACE_DONE] = 0;
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);   // see the other workgroups' list entries and flags
+            }
+        }
+        __syncthreads();
+        if (s_last) test_trace_block<1>(M_, dp, 0, 1);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_test_trace1(const MemberRef *M_, reina_day_t dp) {
@@ -656,7 +683,8 @@ __global__ __launch_bounds__(256) void k_test_trace1(const MemberRef *M_, reina_
 
 // k_open: the first launch of a day.  Workgroup 0 opens the day (prologue_block: snapshot, beds,
 // intervention imports, daily zeroing, then the weekly imports); workgroups 1.. work off the test
-// queue (MODE 1: detection only, MODE 2: detection + level-0 contact tracing) as soon as workgroup 0
+// queue (MODE 1: detection only, MODE 2: detection + level-0 contact tracing, MODE 3: the same with
+// level 1 folded in) as soon as workgroup 0
 // signals that the bookkeeping part is done -- the import placement that follows it touches only
 // never-infected agents and infection counters, the test queue only infected agents and detection
 // counters, so the two run side by side inside one launch.
@@ -668,6 +696,8 @@ __global__ __launch_bounds__(PRO_THREADS) void k_open(const MemberRef *M_, reina
         test_detect_block(M_, dp, blockIdx.x - 1, gridDim.x - 1);
     } else if (MODE == 2) {
         test_trace_block<0>(M_, dp, blockIdx.x - 1, gridDim.x - 1);
+    } else if (MODE == 3) {
+        test_trace_block<0, true>(M_, dp, blockIdx.x - 1, gridDim.x - 1);
     }
 }
 
@@ -2021,6 +2051,12 @@ __global__ __launch_bounds__(256) void k_install(const MemberRef *M_, reina_day_
     }
 }
 
+__global__ void k_noop(int) {}
+__global__ void k_hold(uint64_t ticks) {  // keeps the stream busy for ticks / 100 MHz
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 
@@ -2139,6 +2175,11 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
 int reina_destroy(reina_engine_t *e) {
     if (!e) return REINA_E_INVALID;
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    for (size_t k = 0; k < e->stage.size(); k++) {
+        hipEventSynchronize(e->stage_ev[k]);
+        hipEventDestroy(e->stage_ev[k]);
+        hipHostFree(e->stage[k]);
+    }
     hipFree(e->d_params);
     hipFree(e->d_tables);
     hipFree(e->d_ref);
@@ -2198,10 +2239,30 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
         if (t->count[a] != t->count[0] ||
             std::memcmp(e->h_tables.meta[a], e->h_tables.meta[0], sizeof(uint32_t) * (size_t)t->count[0]) != 0)
             e->uniform_meta = 0;
-    // pageable source: the runtime stages the bytes before returning, so the host copies above
-    // may be overwritten by the next upload while earlier days are still queued on the stream
-    HIP_CHECK(hipMemcpyAsync(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice, s));
+    size_t slot = e->stage.size();
+    for (size_t k = 0; k < e->stage.size(); k++)
+        if (hipEventQuery(e->stage_ev[k]) == hipSuccess) {
+            slot = k;
+            break;
+        }
+    if (slot == e->stage.size()) {
+        if (e->stage.size() < reina_engine::MAX_STAGES) {
+            reina_engine::Stage *st = nullptr;
+            hipEvent_t ev;
+            HIP_CHECK(hipHostMalloc((void **)&st, sizeof(reina_engine::Stage), hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->stage.push_back(st);
+            e->stage_ev.push_back(ev);
+        } else {
+            slot = 0;
+            HIP_CHECK(hipEventSynchronize(e->stage_ev[0]));
+        }
+    }
+    std::memcpy(&e->stage[slot]->p, &e->h_params, sizeof(DevParams));
+    std::memcpy(&e->stage[slot]->t, &e->h_tables, sizeof(Tables));
+    HIP_CHECK(hipMemcpyAsync(e->d_params, &e->stage[slot]->p, sizeof(DevParams), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(e->d_tables, &e->stage[slot]->t, sizeof(Tables), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipEventRecord(e->stage_ev[slot], s));
     return REINA_OK;
 }
 
@@ -2216,8 +2277,10 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         hipLaunchKernelGGL(k_open<0>, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);
     } else {
         const int g = 1 + grid_for(N / 64 + 1, PRO_THREADS, 64);
-        if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            hipLaunchKernelGGL(k_open<2>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);  // detects + traces
+        if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT && N <= 8000000u) {
+            hipLaunchKernelGGL(k_open<3>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);  // detects + traces, both levels
+        } else if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
+            hipLaunchKernelGGL(k_open<2>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);  // detects + traces level 0
             hipLaunchKernelGGL(k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
         } else {
             hipLaunchKernelGGL(k_open<1>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);
@@ -2388,8 +2451,23 @@ int reina_profile_enable(reina_engine_t *e, int enable) {
     if (!e) return REINA_E_INVALID;
     e->profile = enable != 0;
     e->profile_stride = enable > 1 ? (uint32_t)enable : 1u;
-    // create the timing events up front: hipEventCreate inside the timed region costs microseconds each
-    while (e->profile && e->ev_pool.size() < 2048) {
+    // Timestamped dispatches draw completion signals from a pool the HIP runtime grows on demand,
+    // milliseconds per growth step (measured: the first runs with timestamps were 10-15 us/day
+    // slower than later ones of the same process).  Grow it here, outside any timed region: use a
+    // batch of throw-away events on empty kernels and destroy them, which hands their signals back.
+    static bool pool_grown = false;
+    if (e->profile && !pool_grown) {
+        std::vector<hipEvent_t> tmp(1024);
+        for (auto &ev : tmp) HIP_CHECK(hipEventCreate(&ev));
+        // (all of them outstanding at once, behind a kernel that holds the stream for 10 ms)
+        hipLaunchKernelGGL(k_hold, dim3(1), dim3(1), 0, (hipStream_t) nullptr, (uint64_t)1000000);
+        for (size_t k = 0; k + 1 < tmp.size(); k += 2)
+            hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, (hipStream_t) nullptr, tmp[k], tmp[k + 1], 0, 0);
+        HIP_CHECK(hipDeviceSynchronize());
+        for (auto &ev : tmp) hipEventDestroy(ev);
+        pool_grown = true;
+    }
+    while (e->profile && e->ev_pool.size() < 1024) {
         hipEvent_t ev;
         HIP_CHECK(hipEventCreate(&ev));
         e->ev_pool.push_back(ev);

@@ -525,6 +525,44 @@ class Context:
             return out
         return None
 
+    def _run_streamed(self, days, record_history):
+        """run() for an unsharded population: day descriptors are built on the host and handed to
+        the library in growing chunks, so the GPU works on the first days while the host is still
+        turning the intervention schedule into the later ones (table uploads are queued copies from
+        pinned staging, they do not drain the stream either)."""
+        a = self.engine.alloc
+        hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None
+        base = a.ptr(hist) if record_history else None
+        row = 4 * _eng.COUNTER_WORDS
+        self.mobility_history = []
+        pending, issued, chunk = [], 0, 4
+
+        def flush():
+            nonlocal pending, issued, chunk
+            if pending:
+                arr = (_eng.Day * len(pending))(*pending)
+                self.engine.run_day_array(arr, len(pending), base + row * issued if record_history else None)
+                issued += len(pending)
+                pending = []
+                chunk = min(chunk * 2, 64)
+
+        for _ in range(days):
+            self.mobility_history.append(float(self.contact_matrix.mobility_factor))
+            d, changed = self._build_day(None)
+            if changed:
+                flush()
+                self.engine.upload_contact_tables(*self._packed_tables())
+            pending.append(d)
+            self.day += 1
+            if len(pending) >= chunk:
+                flush()
+        flush()
+        if record_history:
+            out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
+            self._raise_on_problem(self.engine.read_counters())
+            return out
+        return None
+
     def run(self, days, record_history=True):
         """Run `days` consecutive days with one library call per stretch of unchanged contact
         tables (the loop of calc/simulation.py:194-270 without per-day host round trips).
@@ -532,7 +570,7 @@ class Context:
         or None; `self.mobility_history[d]` is the mobility factor generate_state() would have
         reported on that day."""
         if self.n_shards == 1 and not self.always_collective:
-            return self.run_plan(self.make_plan(days), record_history)
+            return self._run_streamed(days, record_history)
         a = self.engine.alloc
         hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None
         base = a.ptr(hist) if record_history else 0
