@@ -246,6 +246,25 @@ __device__ void flush_new_infections(const reina_buffers_t &B, int32_t *new_by_a
     __syncthreads();
 }
 
+// The test-queue and weekly-import workgroups share the launch of the day's opening workgroup
+// (k_open): before they add to the counters they wait here until it has taken the history snapshot
+// and zeroed the daily counters.  The wait
+// is one-directional (on a workgroup with a lower index of the same launch, which the dispatcher
+// starts first), and bounded: after 20 ms the day is flagged failed instead of hanging the device.
+__device__ __forceinline__ void wait_day_open(const reina_buffers_t &B, uint32_t day) {
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = wall_clock64();
+        while (__hip_atomic_load(&B.control[REINA_L_DAY_OPEN], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (int32_t)day + 1) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 2000000ull) {  // 100 MHz ticks
+                set_problem(B.counters, REINA_PROBLEM_SYNC_TIMEOUT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_init: _create_agents / _init_stats (main.pyx:1389-1450)
 __global__ void k_init(const MemberRef *M_, int32_t beds, int32_t icu) {
@@ -322,7 +341,8 @@ __device__ __forceinline__ bool import_target(const DevParams *P, const int32_t 
 
 __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const reina_day_t &dp, int pre_init,
                             uint32_t *import_base, uint8_t *placed, uint32_t *s_unplaced,
-                            int32_t *new_by_age, int32_t *new_by_variant, const int32_t *s_age_start) {
+                            int32_t *new_by_age, int32_t *new_by_variant, const int32_t *s_age_start,
+                            bool wait_for_open = false) {
     uint32_t total = 0;
     for (uint32_t b = 0; b < dp.n_import_batches; b++)
         if ((int)dp.import_batches[b].pre_init == pre_init) total += dp.import_batches[b].count;
@@ -382,6 +402,7 @@ __device__ void pro_imports(const DevParams *P, const reina_buffers_t &B, const 
         __syncthreads();
     }
     if (threadIdx.x == 0) *s_unplaced = 0;
+    if (wait_for_open) wait_day_open(B, dp.day);   // agents are placed; the counters follow the daily zeroing
     __syncthreads();
     uint32_t mine = 0;
     for (uint32_t j = threadIdx.x; j < total; j += PRO_THREADS)
@@ -447,7 +468,7 @@ __device__ void pro_vaccinate(const DevParams *P, const reina_buffers_t &B, cons
     }
 }
 
-__device__ __forceinline__ void prologue_block(const MemberRef *M_, const reina_day_t &dp, uint32_t hist_slot) {
+__device__ __forceinline__ void prologue_block(const MemberRef *M_, const reina_day_t &dp, uint32_t hist_slot, int weekly_elsewhere) {
     const MemberRef &mref_ = M_[blockIdx.y];
     const DevParams *P = mref_.P;
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
@@ -463,9 +484,21 @@ __device__ __forceinline__ void prologue_block(const MemberRef *M_, const reina_
     __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
     const int tid = threadIdx.x;
+#ifdef REINA_OPEN_STAMPS
+    const uint64_t ps_t = wall_clock64();
+#endif
     if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
     if (tid < REINA_MAX_AGES) new_by_age[tid] = 0;
     if (tid < REINA_MAX_VARIANTS) new_by_variant[tid] = 0;
+    // (the scalars thread 0 rewrites below are requested now, beside the snapshot loads)
+    int32_t pre_beds = 0, pre_abeds = 0, pre_icu = 0, pre_aicu = 0, pre_qlen = 0;
+    if (tid == 0) {
+        pre_beds = B.counters[SC_IDX(REINA_S_BEDS)];
+        pre_abeds = B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)];
+        pre_icu = B.counters[SC_IDX(REINA_S_ICU_UNITS)];
+        pre_aicu = B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)];
+        pre_qlen = B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
+    }
     // generate_state() is taken BEFORE iterate() (calc/simulation.py:195 vs :270)
     if (history_row)
         for (int k = tid; k < REINA_COUNTER_WORDS; k += PRO_THREADS) history_row[k] = B.counters[k];
@@ -473,10 +506,10 @@ __device__ __forceinline__ void prologue_block(const MemberRef *M_, const reina_
     if (tid == 0) {
         s_import_base = 0;
         B.counters[SC_IDX(REINA_S_DAY)] = (int32_t)dp.day + 1;
-        B.counters[SC_IDX(REINA_S_BEDS)] += dp.add_beds;
-        B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] += dp.add_beds;
-        B.counters[SC_IDX(REINA_S_ICU_UNITS)] += dp.add_icu_units;
-        B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] += dp.add_icu_units;
+        B.counters[SC_IDX(REINA_S_BEDS)] = pre_beds + dp.add_beds;
+        B.counters[SC_IDX(REINA_S_AVAILABLE_BEDS)] = pre_abeds + dp.add_beds;
+        B.counters[SC_IDX(REINA_S_ICU_UNITS)] = pre_icu + dp.add_icu_units;
+        B.counters[SC_IDX(REINA_S_AVAILABLE_ICU)] = pre_aicu + dp.add_icu_units;
     }
     __syncthreads();
     pro_imports(P, B, dp, 1, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
@@ -500,18 +533,47 @@ __device__ __forceinline__ void prologue_block(const MemberRef *M_, const reina_
         B.control[REINA_L_HOSP_ADMIT] = 0;
         B.control[REINA_L_ICU_ADMIT] = 0;
         // HealthcareSystem.iterate: ct_cases_per_day = len(queue) (main.pyx:518-519)
-        B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] = B.control[(dp.day & 1) ? REINA_L_QUEUE1 : REINA_L_QUEUE0];
+        B.counters[SC_IDX(REINA_S_CT_CASES_PER_DAY)] = pre_qlen;
     }
     // the day is open: the test-queue workgroups of the same launch (k_open) may start; what follows
     // (weekly imports) only touches never-infected agents and the infection counters
     __threadfence();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&B.control[REINA_L_DAY_OPEN], (int32_t)dp.day + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef REINA_OPEN_STAMPS
+    if (tid == 0) atomicAdd((unsigned long long *)&B.mirror[5], (unsigned long long)(wall_clock64() - ps_t));
+#endif
     // weekly imports (Population.infect_people_daily, main.pyx:1671-1685) run after init_day's
     // zeroing; vaccination follows the test-queue pass in the reference (main.pyx:547-558) and is
     // launched from k_vaccinate after both.
     __syncthreads();
-    pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
+    if (!weekly_elsewhere)
+        pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start);
+#ifdef REINA_OPEN_STAMPS
+    if (tid == 0) atomicAdd((unsigned long long *)&B.mirror[6], (unsigned long long)(wall_clock64() - ps_t));
+#endif
+}
+
+// The weekly imports in a workgroup of their own (days without intervention imports, whose claim
+// keys they would share): agents are drawn, claimed and infected from the first instruction of the
+// launch; only the counter updates wait for the opening workgroup's daily zeroing.
+__device__ __forceinline__ void weekly_imports_block(const MemberRef *M_, const reina_day_t &dp) {
+    const MemberRef &mref_ = M_[blockIdx.y];
+    const DevParams *P = mref_.P;
+    const reina_buffers_t B = mref_.B;
+    __shared__ uint8_t placed[PRO_MAX_IMPORTS];
+    __shared__ uint32_t s_unplaced;
+    __shared__ uint32_t s_import_base;
+    __shared__ int32_t new_by_age[REINA_MAX_AGES];
+    __shared__ int32_t new_by_variant[REINA_MAX_VARIANTS];
+    __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
+    const int tid = threadIdx.x;
+    if (tid <= REINA_MAX_AGES) s_age_start[tid] = P->age_start[tid];
+    if (tid < REINA_MAX_AGES) new_by_age[tid] = 0;
+    if (tid < REINA_MAX_VARIANTS) new_by_variant[tid] = 0;
+    if (tid == 0) s_import_base = 0;
+    __syncthreads();
+    pro_imports(P, B, dp, 0, &s_import_base, placed, &s_unplaced, new_by_age, new_by_variant, s_age_start, true);
 }
 
 __global__ __launch_bounds__(PRO_THREADS) void k_vaccinate(const MemberRef *M_, reina_day_t dp) {
@@ -534,25 +596,6 @@ __device__ __forceinline__ void queue_append(const DevParams *P, const reina_buf
         return;
     }
     (which ? B.queue1 : B.queue0)[pos] = idx;
-}
-
-// Test-queue workgroups share the launch of the day's opening workgroup (k_open): before they add
-// to the detection counters they wait here until it has taken the history snapshot and zeroed the
-// daily counters.  The wait
-// is one-directional (on a workgroup with a lower index of the same launch, which the dispatcher
-// starts first), and bounded: after 20 ms the day is flagged failed instead of hanging the device.
-__device__ __forceinline__ void wait_day_open(const reina_buffers_t &B, uint32_t day) {
-    if (threadIdx.x == 0) {
-        const uint64_t t0 = wall_clock64();
-        while (__hip_atomic_load(&B.control[REINA_L_DAY_OPEN], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (int32_t)day + 1) {
-            __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 2000000ull) {  // 100 MHz ticks
-                set_problem(B.counters, REINA_PROBLEM_SYNC_TIMEOUT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
 }
 
 // Q1: every queued test is positive (quirk Q8): clear QUEUED, set DETECTED
@@ -601,6 +644,34 @@ __device__ __forceinline__ bool try_queue(const DevParams *P, const reina_buffer
 // Level 0 also performs the detection of its queue entry (k_test_detect's job) in the same pass:
 // every member of today's queue carries QUEUED until its single store replaces it with DETECTED,
 // so a tracer can never re-queue another member, whichever of the two runs first.
+#ifdef REINA_OPEN_STAMPS
+#define OSTAMP(k) do { if (threadIdx.x == 0) { uint64_t t_ = wall_clock64(); atomicAdd((unsigned long long *)&B.mirror[k], (unsigned long long)(t_ - os_t)); os_t = t_; } } while (0)
+#else
+#define OSTAMP(k) do { } while (0)
+#endif
+#define TRACE_STAGE 4096
+// successes of a workgroup are staged in LDS and appended to the global lists with ONE allocation
+// per list at the end (a returning global atomic per success would sit in every lane's dependent
+// chain); overflow of the stage falls back to direct appends
+struct TraceStage {
+    uint32_t n;
+    uint32_t base_q, base_l;
+    uint32_t item[TRACE_STAGE];
+};
+template <int LEVEL>
+__device__ __forceinline__ void trace_accept(const DevParams *P, const reina_buffers_t &B, TraceStage &S, int nxt, uint32_t cand) {
+    const uint32_t pos = atomicAdd(&S.n, 1u);
+    if (pos < TRACE_STAGE) {
+        S.item[pos] = cand;
+        return;
+    }
+    queue_append(P, B, nxt, cand);
+    if (LEVEL == 0) {
+        uint32_t p1 = wave_alloc(&B.control[REINA_L_LEVEL1]);
+        if (p1 < P->max_queue) B.level1[p1] = cand; else set_problem(B.counters, REINA_PROBLEM_QUEUE_OVERFLOW);
+    }
+}
+
 template <int LEVEL, bool FOLD = false>
 __device__ __forceinline__ void test_trace_block(const MemberRef *M_, const reina_day_t &dp, uint32_t bx, uint32_t nbx) {
     const MemberRef &mref_ = M_[blockIdx.y];
@@ -608,17 +679,25 @@ __device__ __forceinline__ void test_trace_block(const MemberRef *M_, const rein
     const reina_buffers_t B = mref_.B;  // by value: pointers live in SGPRs, never re-read after stores
     __shared__ int32_t s_det[REINA_MAX_AGES];
     __shared__ int32_t s_age_start[REINA_MAX_AGES + 1];
+    __shared__ TraceStage S;
     const int cur = dp.day & 1, nxt = cur ^ 1;
     const uint32_t *src = LEVEL == 0 ? (cur ? B.queue1 : B.queue0) : B.level1;
     const int n = LEVEL == 0 ? B.control[cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0] : B.control[REINA_L_LEVEL1];
     if (n <= (int)(bx * blockDim.x)) return;
+#ifdef REINA_OPEN_STAMPS
+    uint64_t os_t = wall_clock64();
+#endif
     if (LEVEL == 0) {
         if (threadIdx.x <= REINA_MAX_AGES) s_age_start[threadIdx.x] = P->age_start[threadIdx.x];
         if (threadIdx.x < REINA_MAX_AGES) s_det[threadIdx.x] = 0;
-        __syncthreads();
     }
+    if (threadIdx.x == 0) S.n = 0;
+    __syncthreads();
     for (int k = bx * blockDim.x + threadIdx.x; k < n; k += nbx * blockDim.x) {
-        uint32_t i = src[k];
+        const uint32_t i = src[k];
+        // everything that depends only on i is requested together
+        const int32_t inf = B.infector[i];
+        int32_t c = B.first_infectee[i];
         uint32_t wi;
         if (LEVEL == 0) {
             const uint32_t w0 = B.hot[i];
@@ -629,28 +708,40 @@ __device__ __forceinline__ void test_trace_block(const MemberRef *M_, const rein
         } else {
             wi = ld_hot(&B.hot[i]);
         }
-        int32_t inf = B.infector[i];
-        if (inf >= 0 && try_queue(P, B, (uint32_t)inf, i, dp)) {
-            queue_append(P, B, nxt, (uint32_t)inf);
-            if (LEVEL == 0) {
-                uint32_t pos = wave_alloc(&B.control[REINA_L_LEVEL1]);
-                if (pos < P->max_queue) B.level1[pos] = (uint32_t)inf; else set_problem(B.counters, REINA_PROBLEM_QUEUE_OVERFLOW);
+        if (inf >= 0 && try_queue(P, B, (uint32_t)inf, i, dp)) trace_accept<LEVEL>(P, B, S, nxt, (uint32_t)inf);
+        if (wi & RH_HASLIST) {
+            while (c >= 0) {
+                const int32_t next = B.next_sibling[c];   // requested beside the candidate's hot word
+                if (try_queue(P, B, (uint32_t)c, i, dp)) trace_accept<LEVEL>(P, B, S, nxt, (uint32_t)c);
+                c = next;
             }
         }
-        if (wi & RH_HASLIST) {
-            for (int32_t c = B.first_infectee[i]; c >= 0; c = B.next_sibling[c]) {
-                if (try_queue(P, B, (uint32_t)c, i, dp)) {
-                    queue_append(P, B, nxt, (uint32_t)c);
-                    if (LEVEL == 0) {
-                        uint32_t pos = wave_alloc(&B.control[REINA_L_LEVEL1]);
-                        if (pos < P->max_queue) B.level1[pos] = (uint32_t)c; else set_problem(B.counters, REINA_PROBLEM_QUEUE_OVERFLOW);
-                    }
+    }
+    __syncthreads();
+    {   // one allocation per list for the whole workgroup, then coalesced copies out of LDS
+        const uint32_t cnt = S.n < TRACE_STAGE ? S.n : TRACE_STAGE;
+        if (threadIdx.x == 0 && cnt) {
+            S.base_q = (uint32_t)atomicAdd(&B.control[nxt ? REINA_L_QUEUE1 : REINA_L_QUEUE0], (int)cnt);
+            if (LEVEL == 0) S.base_l = (uint32_t)atomicAdd(&B.control[REINA_L_LEVEL1], (int)cnt);
+        }
+        __syncthreads();
+        if (cnt) {
+            uint32_t *q = nxt ? B.queue1 : B.queue0;
+            if (S.base_q + cnt > P->max_queue || (LEVEL == 0 && S.base_l + cnt > P->max_queue)) {
+                if (threadIdx.x == 0) set_problem(B.counters, REINA_PROBLEM_QUEUE_OVERFLOW);
+            } else {
+                for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
+                    const uint32_t x = S.item[k];
+                    q[S.base_q + k] = x;
+                    if (LEVEL == 0) B.level1[S.base_l + k] = x;
                 }
             }
         }
     }
+    OSTAMP(LEVEL == 0 ? 1 : 4);
     if (LEVEL == 0) {
-        wait_day_open(B, dp.day);   // (includes the workgroup barrier) counters only after the snapshot + zeroing
+        wait_day_open(B, dp.day);   // (includes a workgroup barrier) counters only after the snapshot + zeroing
+        OSTAMP(2);
         if (threadIdx.x < REINA_MAX_AGES && s_det[threadIdx.x]) {
             atomicAdd(&B.counters[CNT_IDX(REINA_C_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
             atomicAdd(&B.counters[CNT_IDX(REINA_C_ALL_DETECTED, threadIdx.x)], s_det[threadIdx.x]);
@@ -660,11 +751,17 @@ __device__ __forceinline__ void test_trace_block(const MemberRef *M_, const rein
         // small populations: the level-0 workgroup that finishes last walks the level-1 list itself
         // (a few hundred entries) instead of a launch of its own
         __shared__ int s_last;
+        uint32_t busy = ((uint32_t)n + blockDim.x - 1) / blockDim.x;   // workgroups that had queue entries
+        if (busy > nbx) busy = nbx;
+        if (busy == 1) {
+            __syncthreads();   // the only one: its own list writes are visible to itself
+            OSTAMP(3);
+            test_trace_block<1>(M_, dp, 0, 1);
+            return;
+        }
         __threadfence();
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t busy = ((uint32_t)n + blockDim.x - 1) / blockDim.x;   // workgroups that had queue entries
-            if (busy > nbx) busy = nbx;
             const int done = atomicAdd(&B.control[REINA_L_TRACE_DONE], 1) + 1;
             s_last = done == (int)busy;
             if (s_last) {
@@ -673,6 +770,7 @@ __device__ __forceinline__ void test_trace_block(const MemberRef *M_, const rein
             }
         }
         __syncthreads();
+        OSTAMP(3);
         if (s_last) test_trace_block<1>(M_, dp, 0, 1);
     }
 }
@@ -682,22 +780,24 @@ __global__ __launch_bounds__(256) void k_test_trace1(const MemberRef *M_, reina_
 }
 
 // k_open: the first launch of a day.  Workgroup 0 opens the day (prologue_block: snapshot, beds,
-// intervention imports, daily zeroing, then the weekly imports); workgroups 1.. work off the test
+// intervention imports, daily zeroing), workgroup 1 places the weekly imports; workgroups 2.. work off the test
 // queue (MODE 1: detection only, MODE 2: detection + level-0 contact tracing, MODE 3: the same with
 // level 1 folded in) as soon as workgroup 0
 // signals that the bookkeeping part is done -- the import placement that follows it touches only
 // never-infected agents and infection counters, the test queue only infected agents and detection
 // counters, so the two run side by side inside one launch.
 template <int MODE>
-__global__ __launch_bounds__(PRO_THREADS) void k_open(const MemberRef *M_, reina_day_t dp, uint32_t hist_slot) {
+__global__ __launch_bounds__(PRO_THREADS) void k_open(const MemberRef *M_, reina_day_t dp, uint32_t hist_slot, int weekly_own) {
     if (blockIdx.x == 0) {
-        prologue_block(M_, dp, hist_slot);
+        prologue_block(M_, dp, hist_slot, weekly_own);
+    } else if (blockIdx.x == 1) {
+        if (weekly_own) weekly_imports_block(M_, dp);
     } else if (MODE == 1) {
-        test_detect_block(M_, dp, blockIdx.x - 1, gridDim.x - 1);
+        test_detect_block(M_, dp, blockIdx.x - 2, gridDim.x - 2);
     } else if (MODE == 2) {
-        test_trace_block<0>(M_, dp, blockIdx.x - 1, gridDim.x - 1);
+        test_trace_block<0>(M_, dp, blockIdx.x - 2, gridDim.x - 2);
     } else if (MODE == 3) {
-        test_trace_block<0, true>(M_, dp, blockIdx.x - 1, gridDim.x - 1);
+        test_trace_block<0, true>(M_, dp, blockIdx.x - 2, gridDim.x - 2);
     }
 }
 
@@ -2273,17 +2373,21 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
                             uint32_t hist_slot, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
     if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
+    uint32_t n_pre = 0, n_post = 0;
+    for (uint32_t b = 0; b < dp.n_import_batches; b++)
+        (dp.import_batches[b].pre_init ? n_pre : n_post) += dp.import_batches[b].count;
+    const int weekly_own = n_pre == 0 && n_post > 0;   // (intervention imports share the claim keys: same workgroup then)
     if (!e->testing_ever) {
-        hipLaunchKernelGGL(k_open<0>, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);
+        hipLaunchKernelGGL(k_open<0>, dim3(2, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
     } else {
-        const int g = 1 + grid_for(N / 64 + 1, PRO_THREADS, 64);
+        const int g = 2 + grid_for(N / 64 + 1, PRO_THREADS, 64);
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT && N <= 8000000u) {
-            hipLaunchKernelGGL(k_open<3>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);  // detects + traces, both levels
+            hipLaunchKernelGGL(k_open<3>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces, both levels
         } else if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            hipLaunchKernelGGL(k_open<2>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);  // detects + traces level 0
+            hipLaunchKernelGGL(k_open<2>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces level 0
             hipLaunchKernelGGL(k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
         } else {
-            hipLaunchKernelGGL(k_open<1>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot);
+            hipLaunchKernelGGL(k_open<1>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
         }
     }
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
