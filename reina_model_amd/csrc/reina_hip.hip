@@ -191,9 +191,12 @@ __device__ __forceinline__ uint32_t clamp_days(int32_t *counters, int d) {
 
 // person_infect (main.pyx:209-235) + Population.infect (:1576-1582).  `expect` is the susceptible
 // word the caller saw; the CAS makes duplicate winner records install once.
+// `src_word`: the source's hot word if the caller already holds it (saves a dependent load), else 0
+// with src_known = false.
 __device__ bool install_infection(const DevParams *P, const reina_buffers_t &B, const int32_t *age_start, uint32_t t, uint32_t expect,
                                   uint32_t day, uint32_t variant, int32_t src, int fresh,
-                                  uint32_t testing_mode, int32_t *new_by_age, int32_t *new_by_variant) {
+                                  uint32_t testing_mode, int32_t *new_by_age, int32_t *new_by_variant,
+                                  bool src_known = false, uint32_t src_word = 0) {
     int age = age_of(age_start, t, 0, (int)P->nr_ages - 1);
     rp_u4 r = rp_philox(P->k0, P->k1, t, day, RP_P_INFECT, 0);
     float val = rp_uniform24(r.v[0]);
@@ -210,13 +213,13 @@ __device__ bool install_infection(const DevParams *P, const reina_buffers_t &B, 
     atomicAnd(&B.sus_bits[t >> 5], ~(1u << (t & 31u)));
     if (src >= 0) {
         B.infector[t] = src;
-        int old = atomicAdd(&B.n_infected[src], 1);
-        if (ld_hot(&B.hot[src]) & RH_HASLIST) {
-            if (old >= 64) {
-                set_problem(B.counters, 1 /* TOO_MANY_INFECTEES */);
-            } else {
-                B.next_sibling[t] = atomicExch(&B.first_infectee[src], (int32_t)t);
-            }
+        if (!src_known) src_word = ld_hot(&B.hot[src]);
+        // the count and the list head are bumped side by side (two independent round trips); a
+        // 65th infectee fails the whole simulation (TOO_MANY_INFECTEES), so its link does not matter
+        const int old = atomicAdd(&B.n_infected[src], 1);
+        if (src_word & RH_HASLIST) {
+            B.next_sibling[t] = atomicExch(&B.first_infectee[src], (int32_t)t);
+            if (old >= 64) set_problem(B.counters, 1 /* TOO_MANY_INFECTEES */);
         }
     }
     atomicAdd(&new_by_age[age], 1);          // workgroup-local (LDS) histograms,
@@ -1238,11 +1241,28 @@ __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_
         const uint32_t sw = tid * per_w + k;
         cnts[k] = (k < per_w && sw < scan_waves) ? B.work_counts[LIST_EV * REINA_MAX_SCAN_WAVES + sw] : 0u;
     }
+    // the first record of every non-empty slice is requested at once (most slices hold 0 or 1 events);
+    // both passes below use these registers and only go back to memory for a slice's later records
+    // (registers for 4 slices: all of them up to 4096 scanning waves, i.e. populations up to 2 M agents)
+    uint2 first[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        first[k] = make_uint2(0, 0);
+        if (cnts[k]) first[k] = l_ev[scan_slice_base(tid * per_w + k, scan_waves, scan_tiles)];
+    }
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
         if (cnts[k] == 0) continue;
+        if (k < 4) {
+            const uint32_t ty = first[k].y & 3u;
+            mine[0] += ty == 0;
+            mine[1] += ty == 1;
+            mine[2] += ty == 2;
+            mine[3] += ty == 3;
+            if (cnts[k] == 1) continue;
+        }
         const uint32_t base = scan_slice_base(tid * per_w + k, scan_waves, scan_tiles);
-        for (uint32_t j = 0; j < cnts[k]; j++) {
+        for (uint32_t j = k < 4 ? 1 : 0; j < cnts[k]; j++) {
             const uint32_t ty = l_ev[base + j].y & 3u;
             mine[0] += ty == 0;
             mine[1] += ty == 1;
@@ -1314,7 +1334,7 @@ __device__ __forceinline__ void hospital_block(const MemberRef *M_, const reina_
             if (cnts[k] == 0) continue;
             const uint32_t base = scan_slice_base(tid * per_w + k, scan_waves, scan_tiles);
             for (uint32_t j = 0; j < cnts[k]; j++) {
-                const uint2 r = l_ev[base + j];
+                const uint2 r = (k < 4 && j == 0) ? first[k] : l_ev[base + j];
                 const uint64_t prio = rp_priority20(P->k0, P->k1, r.x, dp.day);
                 const uint32_t ty = r.y & 3u;
                 const int p2 = ty == 0 ? pos[0]++ : ty == 1 ? pos[1]++ : ty == 2 ? pos[2]++ : pos[3]++;
@@ -2029,10 +2049,14 @@ __global__ __launch_bounds__(256) void k_install(const MemberRef *M_, reina_day_
                     }
                 }
                 const uint4 cd = cand[bsel + j];
-                if (B.claim[cd.x] != rp_order_key(dp.day, cd.w, cd.y)) continue;
-                uint32_t w = ld_hot(&B.hot[cd.x]);
+                // claim word, target word and source word are requested together
+                const uint64_t cl = ld_claim(&B.claim[cd.x]);
+                const uint32_t w = ld_hot(&B.hot[cd.x]);
+                const uint32_t ws = ld_hot(&B.hot[cd.y]);
+                if (cl != rp_order_key(dp.day, cd.w, cd.y)) continue;
                 if (RH_STATE(w) != RS_SUSCEPTIBLE) continue;  // duplicate record of the same winner
-                install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode, new_by_age, new_by_variant);
+                install_infection(P, B, s_age_start, cd.x, w, dp.day, cd.z, (int32_t)cd.y, 0, dp.testing_mode, new_by_age, new_by_variant,
+                                  true, ws);
             }
         }
         // candidates realised from cross-shard pressure (k_remote), indexed above the slice regions
