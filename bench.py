@@ -56,7 +56,7 @@ def scaled_scenario(variables, total_agents):
     return v, datasets.scaled_population(total_agents)
 
 
-def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=1, preheat_runs=3):
+def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=1, preheat_runs=2):
     import numpy as np
     import torch
     from reina_model_amd import engine as eng
@@ -65,10 +65,7 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
     for rep in range(preheat_runs if preheat else 0):
         # throw-away runs of the same workload (untimed, separate state): bring the GPU out of its
         # idle power state and pay one-time runtime costs before the measured simulation exists.
-        # Measured on ROCm 7.2 (tools/bench_debug.py): each of the first two or three full runs of a
-        # process that carry timestamped dispatches stalls ~7 ms inside ONE of its table uploads (a
-        # runtime-internal pool growing while the host is >1000 dispatches ahead); later runs never
-        # do -- hence three preheat runs, profiled exactly like the timed one.
+        # (event pools, allocator pools, first timestamped dispatches), profiled like the timed one.
         pre = simulation.make_context(variables, age_counts=ages, seed=seed + 1000003 + rep, device=device, comm=comm)
         pre.engine.profile_enable(stride)
         pre.run(preheat, record_history=True)
@@ -159,28 +156,63 @@ print(t0, time.time())
 """
 
 
-def cpu_baseline_all_cores(days, max_procs=64):
+_CPU_HELPER = r"""
+import json, os, subprocess, sys, time
+root, days, procs, go = %(root)r, %(days)d, %(procs)d, %(go)r
+worker = %(worker)r
+while not os.path.exists(go):          # the GPU measurements come first: all-core load slows the host
+    time.sleep(0.05)
+    if os.getppid() == 1:
+        sys.exit(0)
+start = time.time() + 10.0
+ps = [subprocess.Popen([sys.executable, '-c', worker %% dict(root=root, seed=1000 + k, start=start, days=days)],
+                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(procs)]
+spans = []
+for p in ps:
+    out, _ = p.communicate(timeout=600)
+    if p.returncode == 0:
+        a, b = out.decode().split()[-2:]
+        spans.append((float(a), float(b)))
+print(json.dumps(spans))
+"""
+
+
+class CpuAllCores:
     """The reference's Monte-Carlo shape (calc/simulation.py:376: a pool of processes, one
     simulation each) with the sequential C restatement: one HUS simulation per host core, all
-    started together.  Child processes are spawned BEFORE this process touches the GPU."""
-    import subprocess
-    procs = min(os.cpu_count() or 1, max_procs)
-    start = time.time() + 12.0
-    ps = [subprocess.Popen([sys.executable, '-c', _CPU_WORKER % dict(root=ROOT, seed=1000 + k, start=start, days=days)],
-                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(procs)]
-    spans = []
-    for p in ps:
-        out, _ = p.communicate(timeout=600)
-        if p.returncode == 0:
-            a, b = out.decode().split()[-2:]
-            spans.append((float(a), float(b)))
-    if not spans:
-        return None
-    wall = max(b for _, b in spans) - min(a for a, _ in spans)
-    n = 1685983
-    return dict(value=round(n * days * len(spans) / wall, 1), unit='agent-days/s', cores=len(spans), kind='port',
-                sample='%d concurrent sequential simulations (one per core, cores capped at %d), HUS %d agents, '
-                       'first %d days each, %.1f s wall' % (len(spans), max_procs, n, days, wall))
+    started together.  A helper process is spawned BEFORE this process touches the GPU (no exec
+    after GPU initialisation); it starts its workers only when told to, after the GPU measurements,
+    so that the all-core load cannot disturb them."""
+
+    def __init__(self, days, max_procs=64):
+        import subprocess
+        import tempfile
+        self.days = days
+        self.procs = min(os.cpu_count() or 1, max_procs)
+        self.max_procs = max_procs
+        self.go = os.path.join(tempfile.gettempdir(), 'reina_bench_go_%d' % os.getpid())
+        code = _CPU_HELPER % dict(root=ROOT, days=days, procs=self.procs, go=self.go, worker=_CPU_WORKER)
+        self.helper = subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+
+    def run(self):
+        open(self.go, 'w').close()
+        try:
+            out, _ = self.helper.communicate(timeout=900)
+            spans = json.loads(out.decode().strip().splitlines()[-1])
+        except Exception:
+            return None
+        finally:
+            try:
+                os.unlink(self.go)
+            except OSError:
+                pass
+        if not spans:
+            return None
+        wall = max(b for _, b in spans) - min(a for a, _ in spans)
+        n = 1685983
+        return dict(value=round(n * self.days * len(spans) / wall, 1), unit='agent-days/s', cores=len(spans), kind='port',
+                    sample='%d concurrent sequential simulations (one per core, cores capped at %d), HUS %d agents, '
+                           'first %d days each, %.1f s wall' % (len(spans), self.max_procs, n, self.days, wall))
 
 
 def ensemble_line(seeds, days, device):
@@ -228,7 +260,7 @@ def main():
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
     cpu_all = None
     if world_env == 1 and not a.no_cpu and not a.agents and a.cpu_all_cores_days > 0:
-        cpu_all = cpu_baseline_all_cores(a.cpu_all_cores_days)   # before anything initialises the GPU
+        cpu_all = CpuAllCores(a.cpu_all_cores_days)   # helper spawned before anything initialises the GPU; runs last
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
@@ -303,7 +335,9 @@ def main():
             out['cpu_baseline'] = cpu_baseline(copy.deepcopy(VARIABLE_DEFAULTS), hus, a.seed, a.cpu_days)
             out['cpu_baseline']['cores_available'] = os.cpu_count()
             if cpu_all is not None:
-                out['cpu_baseline']['all_cores'] = cpu_all
+                res = cpu_all.run()
+                if res is not None:
+                    out['cpu_baseline']['all_cores'] = res
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 
 #include <climits>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -2176,6 +2177,12 @@ __global__ __launch_bounds__(256) void k_install(const MemberRef *M_, reina_day_
 }
 
 __global__ void k_noop(int) {}
+// table upload: two word copies out of a pinned host buffer (see reina_upload_contact_tables)
+__global__ __launch_bounds__(256) void k_upload(uint32_t *d0, const uint32_t *s0, uint32_t n0, uint32_t *d1, const uint32_t *s1, uint32_t n1) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n0; k += stride) d0[k] = s0[k];
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += stride) d1[k] = s1[k];
+}
 __global__ void k_hold(uint64_t ticks) {  // keeps the stream busy for ticks / 100 MHz
     const uint64_t t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
@@ -2384,8 +2391,16 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     }
     std::memcpy(&e->stage[slot]->p, &e->h_params, sizeof(DevParams));
     std::memcpy(&e->stage[slot]->t, &e->h_tables, sizeof(Tables));
-    HIP_CHECK(hipMemcpyAsync(e->d_params, &e->stage[slot]->p, sizeof(DevParams), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(e->d_tables, &e->stage[slot]->t, sizeof(Tables), hipMemcpyHostToDevice, s));
+    // The transfer is a KERNEL that reads the pinned host slot directly (zero-copy): an ordinary
+    // dispatch in the day stream.  hipMemcpyAsync of the 98 KB table was measured to block the host
+    // for 7-8 ms once per run when >1000 dispatches were queued ahead of it (ROCm 7.2).
+    void *dsrc = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&dsrc, e->stage[slot], 0));
+    static_assert(sizeof(DevParams) % 4 == 0 && sizeof(Tables) % 4 == 0 && offsetof(reina_engine::Stage, t) % 4 == 0, "word copies");
+    const uint32_t *src_w = reinterpret_cast<const uint32_t *>(dsrc);
+    hipLaunchKernelGGL(k_upload, dim3(64), dim3(256), 0, s, reinterpret_cast<uint32_t *>(e->d_params), src_w,
+                       (uint32_t)(sizeof(DevParams) / 4), reinterpret_cast<uint32_t *>(e->d_tables),
+                       src_w + offsetof(reina_engine::Stage, t) / 4, (uint32_t)(sizeof(Tables) / 4));
     HIP_CHECK(hipEventRecord(e->stage_ev[slot], s));
     return REINA_OK;
 }

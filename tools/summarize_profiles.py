@@ -27,10 +27,14 @@ for cfg, key in (('hus', 'hus'), ('50m', '50000000')):
     tr = glob.glob(os.path.join(G, '%s_trace_%s' % (tag, cfg), '*', '*kernel_trace.csv'))
     if tr:
         rows = list(csv.DictReader(open(tr[0])))
+        # the timed region = from the 365th-last k_scan launch on (preheat and warm-up runs come before)
+        scans = sorted(int(r['Start_Timestamp']) for r in rows if r['Kernel_Name'].startswith('k_scan'))
+        t0 = scans[-365] - 60000 if len(scans) >= 365 else 0
+        rows = [r for r in rows if int(r['Start_Timestamp']) >= t0]
         names = sorted(set(r['Kernel_Name'].split('(')[0] for r in rows if r['Kernel_Name'].startswith(('k_', 'void k_'))))
         with open(os.path.join(P, '%s_kernel_by_day_%s.csv' % (tag, cfg)), 'w') as f:
             w = csv.writer(f)
-            w.writerow(['kernel', 'launches', 'mean_us', 'min_us', 'max_us'] + ['day%d_us' % d for d in range(5, 370, 30)])
+            w.writerow(['kernel (timed region only)', 'launches', 'mean_us', 'min_us', 'max_us'] + ['launch%d_us' % d for d in range(5, 370, 30)])
             for n in names:
                 d = np.array([(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000 for r in rows
                               if r['Kernel_Name'].split('(')[0] == n])
