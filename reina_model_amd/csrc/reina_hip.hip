@@ -2176,16 +2176,11 @@ __global__ __launch_bounds__(256) void k_install(const MemberRef *M_, reina_day_
     }
 }
 
-__global__ void k_noop(int) {}
 // table upload: two word copies out of a pinned host buffer (see reina_upload_contact_tables)
 __global__ __launch_bounds__(256) void k_upload(uint32_t *d0, const uint32_t *s0, uint32_t n0, uint32_t *d1, const uint32_t *s1, uint32_t n1) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n0; k += stride) d0[k] = s0[k];
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += stride) d1[k] = s1[k];
-}
-__global__ void k_hold(uint64_t ticks) {  // keeps the stream busy for ticks / 100 MHz
-    const uint64_t t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2594,22 +2589,7 @@ int reina_profile_enable(reina_engine_t *e, int enable) {
     if (!e) return REINA_E_INVALID;
     e->profile = enable != 0;
     e->profile_stride = enable > 1 ? (uint32_t)enable : 1u;
-    // Timestamped dispatches draw completion signals from a pool the HIP runtime grows on demand,
-    // milliseconds per growth step (measured: the first runs with timestamps were 10-15 us/day
-    // slower than later ones of the same process).  Grow it here, outside any timed region: use a
-    // batch of throw-away events on empty kernels and destroy them, which hands their signals back.
-    static bool pool_grown = false;
-    if (e->profile && !pool_grown) {
-        std::vector<hipEvent_t> tmp(1024);
-        for (auto &ev : tmp) HIP_CHECK(hipEventCreate(&ev));
-        // (all of them outstanding at once, behind a kernel that holds the stream for 10 ms)
-        hipLaunchKernelGGL(k_hold, dim3(1), dim3(1), 0, (hipStream_t) nullptr, (uint64_t)1000000);
-        for (size_t k = 0; k + 1 < tmp.size(); k += 2)
-            hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, (hipStream_t) nullptr, tmp[k], tmp[k + 1], 0, 0);
-        HIP_CHECK(hipDeviceSynchronize());
-        for (auto &ev : tmp) hipEventDestroy(ev);
-        pool_grown = true;
-    }
+    // create the timing events up front: hipEventCreate inside a timed region costs microseconds each
     while (e->profile && e->ev_pool.size() < 1024) {
         hipEvent_t ev;
         HIP_CHECK(hipEventCreate(&ev));
