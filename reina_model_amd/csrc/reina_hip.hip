@@ -1818,7 +1818,8 @@ __device__ __forceinline__ void contacts_block(const MemberRef *M_, const reina_
                     const uint32_t start = (uint32_t)S.age_start[cmin], end = (uint32_t)S.age_start[cmax + 1];
                     // uniform member of the range over the WHOLE population: uniform shard, then
                     // uniform agent of that shard (every shard holds 1/G of every age)
-                    const uint32_t dest = r.v[1] % n_shards;
+                    // (an unsharded population skips the two integer divisions: x % 1 = 0, x / 1 = x)
+                    const uint32_t dest = n_shards > 1 ? r.v[1] % n_shards : 0u;
                     if (dest != shard_rank) {
                         // source-side part of did_infect; the destination applies p_sus / psus_max
                         float qv = src_inf * P->psus_max[v] * d.infectiousness_multiplier[v];
@@ -1841,7 +1842,7 @@ __device__ __forceinline__ void contacts_block(const MemberRef *M_, const reina_
                             atomicMin((unsigned long long *)slot, (unsigned long long)rp_order_key(dp.day, hm.v[1] >> 12, src));
                         }
                     } else if (end > start) {
-                        const uint32_t t = start + (r.v[1] / n_shards) % (end - start);
+                        const uint32_t t = start + (n_shards > 1 ? r.v[1] / n_shards : r.v[1]) % (end - start);
                         // 1 bit per agent: the whole table (N/8 bytes) stays in L2 / Infinity Cache
                         if ((B.sus_bits[t >> 5] >> (t & 31u)) & 1u) {
                             const int age_t = age_of(S.age_start, t, cmin, cmax);
@@ -2414,7 +2415,10 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     if (!e->testing_ever) {
         hipLaunchKernelGGL(k_open<0>, dim3(2, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
     } else {
-        const int g = 2 + grid_for(N / 64 + 1, PRO_THREADS, 64);
+        // (groups: the members share the chip, so each gets proportionally fewer workgroups per phase)
+        int tg = grid_for(N / 64 + 1, PRO_THREADS, 64);
+        if (K > 1 && tg > (int)(256 / K)) tg = 256 / K > 0 ? (int)(256 / K) : 1;
+        const int g = 2 + tg;
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT && N <= 8000000u) {
             hipLaunchKernelGGL(k_open<3>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces, both levels
         } else if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
@@ -2443,6 +2447,10 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     {   // bed / ICU events (workgroup 0, latency-bound) beside the contact sampling (workgroups 1..)
         uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
         if (con_blocks > 255) con_blocks = 255;  // with the event workgroup: one resident wave of workgroups on 256 CUs
+        if (K > 1) {  // a group: 256 workgroups for all members together, each staging its tables once for more slices
+            const uint32_t per = 256u / K > 1u ? 256u / K - 1u : 1u;
+            if (con_blocks > per) con_blocks = per;
+        }
         size_t lds = con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards);
         if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
         hipLaunchKernelGGL(k_hosp_contacts, dim3(con_blocks + 1, K), dim3(CON_THREADS), lds, s, refs, dp, scan_waves, scan_tiles,
@@ -2462,6 +2470,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         if (scan_blocks < 1) scan_blocks = 1;
         if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
         int ig = grid_for(N / 64 + 1, 256, 512) * 2;  // even: candidates / deferred lists
+        if (K > 1 && ig > (int)(4096 / K)) ig = (int)(4096 / K) >= 2 ? ((int)(4096 / K) & ~1) : 2;
         hipLaunchKernelGGL(k_install, dim3(ig, K), dim3(256), 0, s, refs, dp, scan_blocks * SCAN_WAVES, scan_tiles);
     }
     HIP_CHECK(hipGetLastError());

@@ -40,6 +40,7 @@ class TorchComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._nccl = dist.get_backend(group) == 'nccl'   # looked up once: this sits on the per-day path
 
     def _as_tensor(self, buf):
         if isinstance(buf, np.ndarray):
@@ -48,7 +49,7 @@ class TorchComm:
 
     def _all_reduce(self, buf, op):
         t = self._as_tensor(buf)
-        if self.dist.get_backend(self.group) == 'nccl' and not t.is_cuda:
+        if self._nccl and not t.is_cuda:
             # RCCL reduces device memory only: stage host-side counter blocks through HBM
             tmp = t.to(self.torch.device('cuda', self.torch.cuda.current_device()))
             self.dist.all_reduce(tmp, op=op, group=self.group)
