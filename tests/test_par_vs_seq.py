@@ -129,3 +129,32 @@ def test_initial_condition_parallel_form_matches_sequential_oracle():
             se = np.sqrt(A[:, d, k].var(ddof=1) / 24 + B[:, d, k].var(ddof=1) / 24)
             tol = 4.0 * se + 0.005 * abs(A[:, d, k].mean()) + 1.0
             assert abs(A[:, d, k].mean() - B[:, d, k].mean()) <= tol, (d, n, A[:, d, k].mean(), B[:, d, k].mean(), tol)
+
+
+@pytest.mark.gpu
+def test_hip_engine_against_the_recorded_reference_runs_at_hus_scale():
+    """The BASELINE configuration itself: 1 685 983 agents, default scenario, 365 days.  24 seeds on
+    the GPU (one engine group) against the SIX runs recorded from the real cythonsim
+    (tests/golden/hus_default_s*.npz), same tolerance: |mean_gpu - mean_ref| <= 4 * sqrt(var_gpu/24 +
+    var_ref/6) + 0.5 % of the reference mean + 1, every 30th day, 11 quantities."""
+    import glob
+    import json
+    from reina_model_amd import datasets, engine as eng, ensemble
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    files = sorted(glob.glob(os.path.join(GOLDEN, 'hus_default_s*.npz')))
+    assert len(files) == 6
+    meta = json.loads(bytes(np.load(files[0])['meta']))
+    ref = np.array([np.load(f)['pop'].sum(axis=2) for f in files]).astype(np.float64)   # [6, 365, 13]
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    hist = ensemble.run_ensemble(v, range(9000, 9024), 365, age_counts=datasets.get_population_for_area(), concurrent=24)
+    A = eng.MAX_AGES
+    names = [n for n in meta['pop13'] if n != 'vaccinated']
+    worst = 0.0
+    for d in range(30, 365, 30):
+        for n in names:
+            g = hist[:, d, eng.C_NAMES.index(n) * A:(eng.C_NAMES.index(n) + 1) * A].sum(axis=1).astype(np.float64)
+            r = ref[:, d, meta['pop13'].index(n)]
+            tol = 4.0 * np.sqrt(g.var(ddof=1) / len(g) + r.var(ddof=1) / len(r)) + 0.005 * abs(r.mean()) + 1.0
+            worst = max(worst, abs(g.mean() - r.mean()) / tol)
+            assert abs(g.mean() - r.mean()) <= tol, (d, n, g.mean(), r.mean(), tol)
+    print('worst |diff|/tol = %.2f' % worst)
