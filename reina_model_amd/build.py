@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libreina_hip.so')
 SOURCES = [os.path.join(CSRC, 'reina_hip.hip')]
-DEPS = SOURCES + [os.path.join(CSRC, 'reina_prims.h'),
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.inc', '.h'))] + [
                   os.path.join(os.path.dirname(HERE), 'include', 'reina_hip.h')]
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-std=c++17', '-ffp-contract=off',
                '-fno-fast-math']

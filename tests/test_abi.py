@@ -55,7 +55,7 @@ def test_product_package_never_references_the_oracle():
     pkg = os.path.join(ROOT, 'reina_model_amd')
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
-            if fn.endswith(('.py', '.hip', '.h', '.cpp')):
+            if fn.endswith(('.py', '.hip', '.h', '.inc', '.cpp')):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text, fn
                 assert 'libreina_par' not in text and 'libreina_seq' not in text, fn
