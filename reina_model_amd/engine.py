@@ -227,7 +227,7 @@ class Engine:
             queue0=a.zeros(config.max_queue, np.uint32), queue1=a.zeros(config.max_queue, np.uint32),
             level1=a.zeros(config.max_queue, np.uint32), hosp_events=a.zeros(MAX_HOSP_EVENTS, np.uint64),
             pressure=a.zeros(PRESSURE_WORDS, np.int32),
-            mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 8, np.uint64),
+            mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 32, np.uint64),
             work_counts=a.zeros(5 * MAX_SCAN_WAVES, np.uint32),
             scan_lists=a.zeros(4 * config.max_work_items, np.uint32),
             sus_bits=a.zeros((n + 31) // 32 + 1, np.uint32),
