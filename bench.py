@@ -270,8 +270,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # (test hooks: REINA_BENCH_BACKEND=gloo REINA_BENCH_ONE_GPU=1 lets two ranks share the single GPU
+        # of a test box to exercise this path; the driver's runs use nccl, one GPU per rank)
+        if os.environ.get('REINA_BENCH_ONE_GPU'):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('REINA_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     device = 'cuda:%d' % local_rank
 
     from reina_model_amd import datasets
@@ -330,7 +338,7 @@ def main():
             }
         if not a.no_ensemble and world == 1 and not a.agents:
             out['ensemble'] = ensemble_line(a.ensemble_seeds, a.steps, device)
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:   # the CPU baseline is an N=1 figure
             hus = datasets.get_population_for_area()
             out['cpu_baseline'] = cpu_baseline(copy.deepcopy(VARIABLE_DEFAULTS), hus, a.seed, a.cpu_days)
             out['cpu_baseline']['cores_available'] = os.cpu_count()
