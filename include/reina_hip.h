@@ -15,6 +15,7 @@
 #ifndef REINA_HIP_H
 #define REINA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -251,6 +252,15 @@ int reina_set_initial_state(reina_engine_t *e, const reina_initial_state_t *ic, 
 int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t *t, void *stream);
 /* replaces Context.iterate() for one day (main.pyx:2011-2018) */
 int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream);
+/* In-stream collective for a sharded population: `allreduce` has the signature of RCCL's
+ * ncclAllReduce (sendbuff, recvbuff, count, datatype, op, comm, stream) and is called by
+ * reina_step_day / reina_run_days* between the two halves of every day as
+ * allreduce(pressure, pressure, REINA_PRESSURE_WORDS, 2 = ncclInt32, 0 = ncclSum, comm, stream), i.e.
+ * on the day stream itself: no host round trip, no second stream.  The library does not link RCCL;
+ * the caller hands in the function and its communicator (NULL, NULL switches it off). */
+typedef int (*reina_allreduce_fn)(const void *sendbuff, void *recvbuff, size_t count, int datatype, int op,
+                                  void *comm, void *stream);
+int reina_set_collective(reina_engine_t *e, reina_allreduce_fn allreduce, void *comm);
 /* the same day in two halves for a sharded population: `begin` runs everything up to and including
  * contact sampling and leaves this shard's outgoing pressure in buffers.pressure; the caller sums
  * `pressure` over all shards (ncclAllReduce / torch.distributed.all_reduce, the ONLY per-day

@@ -38,6 +38,8 @@ typedef struct {
     uint32_t n_ranges;
     int32_t range_min[REINA_MAX_RANGES], range_max[REINA_MAX_RANGES];
     float psus_max[REINA_MAX_VARIANTS];
+    reina_allreduce_fn coll_fn;
+    void *coll_comm;
 } Par;
 
 #define CNT(e, c, age) ((e)->buf.counters[(c) * REINA_MAX_AGES + (age)])
@@ -955,9 +957,17 @@ int par_step_day_end(Par *e, const reina_day_t *dp, void *stream) {
     return 0;
 }
 
+int par_set_collective(Par *e, reina_allreduce_fn fn, void *comm) {
+    e->coll_fn = fn;
+    e->coll_comm = comm;
+    return 0;
+}
+
 int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
     int rc = par_step_day_begin(e, dp, stream);
     if (rc) return rc;
+    if (e->coll_fn && e->coll_fn(e->buf.pressure, e->buf.pressure, REINA_PRESSURE_WORDS, 2, 0, e->coll_comm, stream) != 0)
+        return REINA_E_INVALID;
     return par_step_day_end(e, dp, stream);
 }
 

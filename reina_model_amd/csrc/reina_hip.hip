@@ -353,9 +353,25 @@ int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) 
     return launch_day_end(e, e->d_ref, 1, *day, (hipStream_t)stream);
 }
 
+int reina_set_collective(reina_engine_t *e, reina_allreduce_fn allreduce, void *comm) {
+    if (!e) return REINA_E_INVALID;
+    e->coll_fn = allreduce;
+    e->coll_comm = comm;
+    return REINA_OK;
+}
+
 int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
     int rc = reina_step_day_begin(e, day, stream);
     if (rc) return rc;
+    if (e->coll_fn) {
+        // the only per-day exchange of a sharded population, queued on the day stream itself
+        const int r = e->coll_fn(e->buf.pressure, e->buf.pressure, REINA_PRESSURE_WORDS, 2 /* ncclInt32 */, 0 /* ncclSum */,
+                                 e->coll_comm, stream);
+        if (r != 0) {
+            g_last_error = "collective failed with code " + std::to_string(r);
+            return REINA_E_HIP;
+        }
+    }
     return reina_step_day_end(e, day, stream);
 }
 

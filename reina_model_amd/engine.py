@@ -44,7 +44,7 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 32
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
-                 'step_day', 'step_day_begin', 'step_day_end', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
+                 'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
                  'group_create', 'group_destroy', 'group_upload_contact_tables', 'group_run_days',
                  'last_error', 'abi_version')
 
@@ -137,6 +137,7 @@ def bind_abi(lib, prefix):
     f['step_day'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['step_day_begin'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['step_day_end'].argtypes = [vp, ctypes.POINTER(Day), vp]
+    f['set_collective'].argtypes = [vp, vp, vp]
     f['run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp]
     f['run_days_hist'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp, vp]
     f['read_counters'].argtypes = [vp, vp, vp]
@@ -276,6 +277,10 @@ class Engine:
 
     def step_day(self, day):
         self._check(self.f['step_day'](self._h, ctypes.byref(day), self.alloc.stream()), 'step_day')
+
+    def set_collective(self, fn_ptr, comm_ptr):
+        """in-stream pressure all-reduce: address of an ncclAllReduce-compatible function + its communicator"""
+        self._check(self.f['set_collective'](self._h, fn_ptr, comm_ptr), 'set_collective')
 
     def step_day_begin(self, day):
         self._check(self.f['step_day_begin'](self._h, ctypes.byref(day), self.alloc.stream()), 'step_day_begin')

@@ -202,6 +202,7 @@ class Context:
         self.comm = comm
         # testing aid: take the begin / all-reduce / end path even with a single shard
         self.always_collective = bool(comm is not None and getattr(comm, 'always_collective', False))
+        self._direct = getattr(comm, 'direct', None) if comm is not None else None
         self.shard_rank = comm.rank if comm is not None else 0
         self.n_shards = comm.world if comm is not None else 1
         self._split = lambda x: split_count(x, self.shard_rank, self.n_shards)
@@ -290,6 +291,10 @@ class Context:
         self._pending_icu = 0
         self._keep = []
         self._iv_index = None
+        # sharded with a communicator of our own: the engine queues the pressure all-reduce itself
+        self._in_stream = self._direct is not None and (self.n_shards > 1 or self.always_collective)
+        if self._in_stream:
+            self.engine.set_collective(self._direct.fn_ptr, self._direct.comm_ptr)
         # main.pyx:1780-1781: the initial condition is applied last, before any intervention exists
         if ipc is not None and ipc.has_initial_state():
             self._set_initial_state(ipc)
@@ -462,7 +467,7 @@ class Context:
     # ------------------------------------------------------------------ day stepping
     # main.pyx:2011-2018
     def _step(self, d):
-        if self.n_shards == 1 and not self.always_collective:
+        if self._in_stream or (self.n_shards == 1 and not self.always_collective):
             self.engine.step_day(d)
         else:
             # the ONLY per-day collective: sum the cross-shard infection pressure (2048 int32)
@@ -526,7 +531,8 @@ class Context:
         return None
 
     def _run_streamed(self, days, record_history):
-        """run() for an unsharded population: day descriptors are built on the host and handed to
+        """run() for an unsharded population, or a sharded one whose engine queues the per-day
+        all-reduce itself (reina_set_collective): day descriptors are built on the host and handed to
         the library in growing chunks, so the GPU works on the first days while the host is still
         turning the intervention schedule into the later ones (table uploads are queued copies from
         pinned staging, they do not drain the stream either)."""
@@ -558,8 +564,12 @@ class Context:
                 flush()
         flush()
         if record_history:
-            out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
-            self._raise_on_problem(self.engine.read_counters())
+            if self.n_shards == 1 and not self.always_collective:
+                out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
+                self._raise_on_problem(self.engine.read_counters())
+            else:   # sharded: rows are summed over the shards when exported
+                out = self._reduce_counter_rows(hist, days)
+                self._raise_on_problem(self._read_counters_global())
             return out
         return None
 
@@ -569,7 +579,7 @@ class Context:
         Returns history[days, COUNTER_WORDS] (row d = counters BEFORE day d ran) as a host array,
         or None; `self.mobility_history[d]` is the mobility factor generate_state() would have
         reported on that day."""
-        if self.n_shards == 1 and not self.always_collective:
+        if self._in_stream or (self.n_shards == 1 and not self.always_collective):
             return self._run_streamed(days, record_history)
         a = self.engine.alloc
         hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None

@@ -29,8 +29,52 @@ def split_population(age_counts, rank, world):
     return np.asarray([split_count(c, rank, world) for c in age_counts], dtype=np.int64)
 
 
+class DirectRccl:
+    """An RCCL communicator of our own, driven through ctypes: its `ncclAllReduce` is handed to the
+    engine (reina_set_collective), which queues the per-day pressure all-reduce on the DAY STREAM
+    itself -- torch.distributed's all_reduce runs on a stream of its own and costs two cross-stream
+    event waits plus Python time per day.  The library is the RCCL PyTorch itself loaded
+    (torch/lib/librccl.so); the unique id travels through the existing torch.distributed group."""
+
+    def __init__(self, dist, group, rank, world):
+        import ctypes
+        import os
+        import torch
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        self.lib = ctypes.CDLL(path)
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [('internal', ctypes.c_char * 128)]
+
+        uid = UniqueId()
+        if rank == 0:
+            rc = self.lib.ncclGetUniqueId(ctypes.byref(uid))
+            if rc != 0:
+                raise RuntimeError('ncclGetUniqueId failed: %d' % rc)
+        box = [bytes(bytearray(uid)) if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        self.comm = ctypes.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        rc = self.lib.ncclCommInitRank(ctypes.byref(self.comm), int(world), uid, int(rank))
+        if rc != 0:
+            raise RuntimeError('ncclCommInitRank failed: %d' % rc)
+        self.fn_ptr = ctypes.cast(self.lib.ncclAllReduce, ctypes.c_void_p).value
+        self.comm_ptr = self.comm.value
+
+    def close(self):
+        import ctypes
+        if getattr(self, 'comm', None) is not None and self.comm.value:
+            self.lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
 class TorchComm:
-    """torch.distributed wrapper: `nccl` (= RCCL on ROCm) for HBM tensors, `gloo` for host arrays."""
+    """torch.distributed wrapper: `nccl` (= RCCL on ROCm) for HBM tensors, `gloo` for host arrays.
+    With the nccl backend the per-day exchange bypasses torch (DirectRccl, REINA_DIRECT_RCCL=0 turns
+    that off); counter reductions at export time keep using torch.distributed."""
 
     def __init__(self, group=None):
         import torch
@@ -41,6 +85,15 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._nccl = dist.get_backend(group) == 'nccl'   # looked up once: this sits on the per-day path
+        self.direct = None
+        import os
+        if self._nccl and os.environ.get('REINA_DIRECT_RCCL', '1') != '0':
+            try:
+                self.direct = DirectRccl(dist, group, self.rank, self.world)
+            except Exception as e:   # fall back to torch.distributed for the per-day exchange
+                import sys
+                print('reina: direct RCCL communicator unavailable (%s); using torch.distributed' % e, file=sys.stderr)
+                self.direct = None
 
     def _as_tensor(self, buf):
         if isinstance(buf, np.ndarray):

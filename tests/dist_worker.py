@@ -36,6 +36,8 @@ def main():
     device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', rank)) if backend == 'nccl' else 'cpu'
     comm = sharding.TorchComm()
     comm.always_collective = True  # exercise begin / all-reduce / end even when world == 1
+    if rank == 0:
+        print('direct_rccl=%s' % (comm.direct is not None), flush=True)
     ctx = simulation.make_context(v, age_counts=ages, seed=21, engine_factory=factory, device=device, comm=comm)
     hist = ctx.run(days)
     final = ctx.generate_state()

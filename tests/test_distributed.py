@@ -18,11 +18,12 @@ def _free_port():
     return p
 
 
-def _launch(world, backend, days, total, timeout=600):
+def _launch(world, backend, days, total, timeout=600, extra_env=None):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'tests', 'dist_worker.py'), backend, str(days), str(total)]
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1')
+    env.update(extra_env or {})
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
@@ -53,3 +54,14 @@ def test_nccl_single_rank_exercises_the_collective_path():
     r = _launch(1, 'nccl', 80, 40000)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'DIST_OK world=1' in r.stdout
+    # ... and it went through the engine's in-stream collective (our own RCCL communicator,
+    # ncclAllReduce queued on the day stream by reina_step_day)
+    assert 'direct_rccl=True' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_nccl_single_rank_torch_distributed_fallback():
+    """the same with REINA_DIRECT_RCCL=0: the per-day exchange through torch.distributed.all_reduce"""
+    r = _launch(1, 'nccl', 80, 40000, extra_env={'REINA_DIRECT_RCCL': '0'})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'DIST_OK world=1' in r.stdout and 'direct_rccl=False' in r.stdout

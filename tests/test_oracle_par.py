@@ -176,3 +176,32 @@ def test_initial_condition_on_a_sharded_population():
     assert tot('infected') + tot('recovered') + tot('dead') == tot('all_infected')
     for _ in range(5):
         sharding.step_shards_together(ctxs)
+
+
+def test_in_stream_collective_hook_is_called_once_per_day():
+    """reina_set_collective (par_ twin): the library calls the ncclAllReduce-shaped function between
+    the two halves of every day with (pressure, pressure, PRESSURE_WORDS, int32, sum, comm, stream)"""
+    import copy
+    import ctypes
+    import numpy as np
+    import par_backend
+    from reina_model_amd import datasets, engine as eng, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=8, icu_units=2)
+    ages = datasets.scaled_population(6000)
+    calls = []
+    FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                          ctypes.c_void_p, ctypes.c_void_p)
+
+    def fake_allreduce(send, recv, count, dtype, op, comm, stream):
+        calls.append((send == recv, count, dtype, op, comm))
+        return 0
+
+    cb = FN(fake_allreduce)
+    a = simulation.make_context(v, age_counts=ages, seed=3, engine_factory=par_backend.par_engine_factory)
+    b = simulation.make_context(v, age_counts=ages, seed=3, engine_factory=par_backend.par_engine_factory)
+    b.engine.set_collective(ctypes.cast(cb, ctypes.c_void_p).value, 1234)
+    ha, hb = a.run(40), b.run(40)
+    assert np.array_equal(ha, hb)
+    assert len(calls) == 40 and all(c == (True, eng.PRESSURE_WORDS, 2, 0, 1234) for c in calls)
