@@ -54,8 +54,11 @@ class ContactMatrix:
         self.mobility_factor = np.float32(1.0)
         self.mobility_factor_changed = False
         self.mask_probabilities = np.zeros((nr_ages, len(PLACES)), dtype=np.float64)
-        self.tables = None
-        self.generate_contact_probabilities()
+        # the tables before any mobility factor depend only on the rows: built once per parsed set
+        if len(parsed) < 3:
+            parsed = parsed + (self.generate_contact_probabilities(),)
+            _parsed_cache[key] = parsed
+        self.tables = parsed[2]
 
     @staticmethod
     def _parse(contacts_per_day, nr_ages):

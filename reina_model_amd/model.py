@@ -85,7 +85,21 @@ def _cv_div(a, b):
     return [(x[0], x[1] / y[1]) for x, y in zip(a, b)]
 
 
+_disease_cache = {}
+
+
 def build_disease_struct(disease_params, nr_ages, imported_infection_ages):
+    """Memoised on the parameter VALUES: ensemble members share one scenario."""
+    key = (repr(sorted(disease_params.items(), key=lambda kv: kv[0])), nr_ages, repr(imported_infection_ages))
+    hit = _disease_cache.get(key)
+    if hit is None:
+        if len(_disease_cache) > 8:
+            _disease_cache.clear()
+        hit = _disease_cache[key] = _build_disease_struct(disease_params, nr_ages, imported_infection_ages)
+    return hit   # (Disease struct, variant names): treated as read-only by every user
+
+
+def _build_disease_struct(disease_params, nr_ages, imported_infection_ages):
     """Disease.__init__ / variant_init (main.pyx:820-881) -> reina_disease_t."""
     d = _eng.Disease()
     variants = [dict(disease_params)]
