@@ -225,6 +225,15 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     std::memcpy(e->h_params.range_max, t->range_max, sizeof(t->range_max));
     std::memcpy(e->h_tables.thr, t->threshold, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
     std::memcpy(e->h_tables.meta, t->meta, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
+    for (uint32_t a = 0; a < A; a++) {
+        const int cnt = t->count[a];
+        int idx = 0;
+        for (uint32_t b = 0; b < 256; b++) {
+            const uint32_t floor_ = b << 24;
+            while (idx < cnt - 1 && e->h_tables.thr[a][idx] <= floor_) idx++;   // thresholds are non-decreasing
+            e->h_tables.guide[a][b] = (uint8_t)(cnt > 0 ? idx : 0);
+        }
+    }
     e->uniform_meta = 1;  // every participant age lists the same (place, contact range) sequence?
     for (uint32_t a = 1; a < A && e->uniform_meta; a++)
         if (t->count[a] != t->count[0] ||
