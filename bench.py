@@ -305,6 +305,24 @@ def main():
     n_agents = total_agents // world   # agents one k_scan launch streams on this rank
     value = total_agents * a.steps / dt
 
+    large_sharded = None
+    if world > 1 and not a.no_large and not a.agents:
+        # BASELINE configs[3] shape on the same ranks: 50 M agents per GPU (4 x 10^8 on 8), sharded
+        vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.large_agents * world)
+        dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, dist,
+                                         preheat=min(a.preheat_days, 120), stride=a.time_every, preheat_runs=1)
+        t = torch.tensor([dtl], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dtl = float(t.item())
+        tot_l = int(_np.asarray(agesl).sum())
+        large_sharded = {
+            'workload': 'synthetic %d agents (%d per GPU, BASELINE configs[3] shape), default scenario scaled, %d days' % (
+                tot_l, tot_l // world, a.steps),
+            'value': round(tot_l * a.steps / dtl, 1), 'unit': 'agent-days/s', 'ms_per_step': round(dtl * 1000 / a.steps, 6),
+            'roofline': roofline_obj(tot_l // world, a.steps, profl, statsl, a.time_every),
+            'final_all_infected': statsl['final_all_infected'],
+        }
+
     out = None
     if rank == 0:
         out = {
@@ -336,6 +354,8 @@ def main():
                 'roofline': roofline_obj(nl, a.steps, profl, statsl, a.time_every),
                 'final_all_infected': statsl['final_all_infected'],
             }
+        if large_sharded is not None:
+            out['large'] = large_sharded
         if not a.no_ensemble and world == 1 and not a.agents:
             out['ensemble'] = ensemble_line(a.ensemble_seeds, a.steps, device)
         if not a.no_cpu and world == 1:   # the CPU baseline is an N=1 figure

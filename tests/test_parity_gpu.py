@@ -334,3 +334,26 @@ def test_large_bed_event_sets():
     assert s['available_hospital_beds'] == 0 and s['available_icu_units'] == 0
     c = gpu.per_age_counters()
     assert c['all_infected'].sum() > 1_000_000   # the wave is big enough for > 1024 events a day
+
+
+def test_sharded_population_at_config3_scale():
+    """BASELINE configs[3] shape on one GPU: 4 shards x 25 M agents (10^8 in total) stepped in
+    lock-step through the epidemic peak -- capacities of the cross-shard candidate region, the
+    mirror table and the bed-event list hold (no problem flag), and agents are conserved."""
+    import bench
+    from reina_model_amd import sharding
+    v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 100_000_000)
+    G = 4
+    members = []
+    ctxs = [simulation.make_context(v, age_counts=ages, seed=2, comm=sharding.InProcessComm(r, G, members)) for r in range(G)]
+    A = eng.MAX_AGES
+    n = int(np.asarray(ages).sum())
+    for d in range(140):
+        sharding.step_shards_together(ctxs)
+        if d % 35 == 34 or d == 139:
+            c = sharding.reduce_counters(ctxs)
+            tot = lambda name: int(c[eng.C_NAMES.index(name) * A:(eng.C_NAMES.index(name) + 1) * A].sum())
+            assert tot('susceptible') + tot('infected') + tot('recovered') + tot('dead') == n, d
+            for ctx in ctxs:
+                ctx._raise_on_problem(ctx.engine.read_counters())
+    assert tot('all_infected') > 5_000_000
