@@ -56,12 +56,22 @@ def scaled_scenario(variables, total_agents):
     return v, datasets.scaled_population(total_agents)
 
 
+_COMM = []
+
+
+def _shared_comm(sharding):
+    """one communicator (torch.distributed group + our RCCL communicator) for every run of this process"""
+    if not _COMM:
+        _COMM.append(sharding.TorchComm())
+    return _COMM[0]
+
+
 def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=1, preheat_runs=2):
     import numpy as np
     import torch
     from reina_model_amd import engine as eng
     from reina_model_amd import sharding, simulation
-    comm = sharding.TorchComm() if dist is not None else None
+    comm = _shared_comm(sharding) if dist is not None else None
     for rep in range(preheat_runs if preheat else 0):
         # throw-away runs of the same workload (untimed, separate state): bring the GPU out of its
         # idle power state and pay one-time runtime costs before the measured simulation exists.
