@@ -266,6 +266,8 @@ def main():
     ap.add_argument('--preheat-days', type=int, default=365,
                     help='days of a throw-away simulation run before the measured one (GPU clocks, one-time costs)')
     a = ap.parse_args()
+    if a.steps < 8 * a.time_every:      # short runs: at least ~8 timestamped launches, every day if need be
+        a.time_every = max(1, a.steps // 8)
 
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
     cpu_all = None
