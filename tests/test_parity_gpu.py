@@ -244,7 +244,7 @@ def _random_scenario(rng):
     return v, datasets.scaled_population(total), days, ivs
 
 
-@pytest.mark.parametrize('case', range(12))
+@pytest.mark.parametrize('case', range(20))
 def test_random_scenarios(case):
     """Randomised scenarios (all intervention types, odd capacities incl. zero beds / ICU units,
     random age windows and places): HIP == oracle B bit for bit."""
