@@ -16,10 +16,10 @@ from reina_model_amd.variables import VARIABLE_DEFAULTS
 pytestmark = pytest.mark.gpu
 
 
-def _pair(variables, ages, seed, interventions=None):
+def _pair(variables, ages, seed, interventions=None, ipc=None):
     import par_backend
-    gpu = simulation.make_context(variables, age_counts=ages, seed=seed, interventions=interventions)
-    cpu = simulation.make_context(variables, age_counts=ages, seed=seed, interventions=interventions,
+    gpu = simulation.make_context(variables, age_counts=ages, seed=seed, interventions=interventions, ipc=ipc)
+    cpu = simulation.make_context(variables, age_counts=ages, seed=seed, interventions=interventions, ipc=ipc,
                                   engine_factory=par_backend.par_engine_factory)
     return gpu, cpu
 
@@ -56,8 +56,8 @@ def _assert_state_equal(gpu, cpu):
         assert chain(fa, na) == chain(fb, nb)
 
 
-def _run_and_compare(variables, ages, seed, days, interventions=None, chunk=None):
-    gpu, cpu = _pair(variables, ages, seed, interventions)
+def _run_and_compare(variables, ages, seed, days, interventions=None, chunk=None, ipc=None):
+    gpu, cpu = _pair(variables, ages, seed, interventions, ipc)
     done = 0
     chunk = chunk or days
     from reina_model_amd.model import SimulationFailed
@@ -241,16 +241,22 @@ def _random_scenario(rng):
             ivs.append([t, when, int(rng.integers(1, 4))])
         else:
             ivs.append([t, when])
-    return v, datasets.scaled_population(total), days, ivs
+    ipc = None
+    if rng.random() < 0.35:   # an initial population condition (set_initial_state)
+        ipc = dict(dead=int(rng.integers(0, 6)), in_icu=int(rng.integers(0, 8)), in_ward=int(rng.integers(0, 15)),
+                   confirmed_cases=int(rng.integers(0, 300)), incubating=int(rng.integers(0, 80)),
+                   ill=int(rng.integers(0, 60)), recovered=int(rng.integers(0, 400)))
+    return v, datasets.scaled_population(total), days, ivs, ipc
 
 
 @pytest.mark.parametrize('case', range(20))
 def test_random_scenarios(case):
     """Randomised scenarios (all intervention types, odd capacities incl. zero beds / ICU units,
-    random age windows and places): HIP == oracle B bit for bit."""
+    random age windows and places, a third of them with an initial population condition): HIP ==
+    oracle B bit for bit."""
     rng = np.random.default_rng(1000 + case)
-    v, ages, days, ivs = _random_scenario(rng)
-    _run_and_compare(v, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40)
+    v, ages, days, ivs, ipc = _random_scenario(rng)
+    _run_and_compare(v, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
 
 
 def test_engine_group_equals_individual_members():
