@@ -109,6 +109,11 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     }
     reina_engine *e = new reina_engine();
     e->cfg = *cfg;
+    {   // compute units of the current device: grids of one-workgroup-per-CU kernels are sized to it
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 1)
+            e->n_cus = (uint32_t)cus;
+    }
     std::memset(&e->h_params, 0, sizeof(DevParams));
     std::memset(&e->h_tables, 0, sizeof(Tables));
     e->h_params.dis = *disease;
@@ -290,7 +295,7 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     } else {
         // (groups: the members share the chip, so each gets proportionally fewer workgroups per phase)
         int tg = grid_for(N / 64 + 1, PRO_THREADS, 64);
-        if (K > 1 && tg > (int)(256 / K)) tg = 256 / K > 0 ? (int)(256 / K) : 1;
+        if (K > 1 && tg > (int)(e->n_cus / K)) tg = e->n_cus / K > 0 ? (int)(e->n_cus / K) : 1;
         const int g = 2 + tg;
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT && N <= 8000000u) {
             hipLaunchKernelGGL(k_open<3>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces, both levels
@@ -319,9 +324,9 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     }
     {   // bed / ICU events (workgroup 0, latency-bound) beside the contact sampling (workgroups 1..)
         uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
-        if (con_blocks > 255) con_blocks = 255;  // with the event workgroup: one resident wave of workgroups on 256 CUs
+        if (con_blocks > e->n_cus - 1) con_blocks = e->n_cus - 1;  // with the event workgroup: one resident wave of workgroups (256 CUs on MI355X)
         if (K > 1) {  // a group: 256 workgroups for all members together, each staging its tables once for more slices
-            const uint32_t per = 256u / K > 1u ? 256u / K - 1u : 1u;
+            const uint32_t per = e->n_cus / K > 1u ? e->n_cus / K - 1u : 1u;
             if (con_blocks > per) con_blocks = per;
         }
         size_t lds = con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards);
