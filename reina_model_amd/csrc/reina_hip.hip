@@ -331,8 +331,12 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         }
         size_t lds = con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards);
         if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
+        // slices per contact wave and step: 1 while every slice has a wave of its own, up to 8 otherwise
+        uint32_t group_slices = scan_waves / (con_blocks * CON_WAVES);
+        if (group_slices < 4) group_slices = 1;   // (measured: grouping 2 dense slices of a 50 M population costs more than it fills)
+        if (group_slices > 8) group_slices = 8;
         hipLaunchKernelGGL(k_hosp_contacts, dim3(con_blocks + 1, K), dim3(CON_THREADS), lds, s, refs, dp, scan_waves, scan_tiles,
-                           e->uniform_meta);
+                           e->uniform_meta, group_slices);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
