@@ -279,6 +279,22 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     return REINA_OK;
 }
 
+// scanning waves of one engine instance: one 512-agent tile per wave (small populations) up to 8192
+// waves; members of a group share the chip, so each gets its part of ~2048 workgroups and its
+// waves walk several tiles (every later kernel takes the wave count as a parameter)
+static uint32_t scan_blocks_for(uint32_t n_agents, uint32_t K) {
+    const uint32_t scan_tiles = ((n_agents >> 2) + 127u) / 128u;
+    uint32_t b = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (b < 1) b = 1;
+    if (b > REINA_MAX_SCAN_WAVES / SCAN_WAVES) b = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
+    if (K > 1) {
+        uint32_t per = (REINA_MAX_SCAN_WAVES / SCAN_WAVES) / K;
+        if (per < 16) per = 16;
+        if (b > per) b = per;
+    }
+    return b;
+}
+
 // One day's launches for K engine instances at once (K = 1: a single engine; K > 1: a group of
 // identically configured engines, one launch per phase for all of them, member = blockIdx.y).
 // `e` is the representative engine: geometry, scenario flags, optional second stream.
@@ -309,9 +325,7 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
     // scan geometry: tiles of 512 agents, as many waves as tiles (small populations) up to 8192
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-    uint32_t scan_blocks = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;  // one 512-agent tile per wave until the grid cap
-    if (scan_blocks < 1) scan_blocks = 1;
-    if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
+    const uint32_t scan_blocks = scan_blocks_for(N, K);
     const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
     if (e->profile && K == 1 && dp.day % e->profile_stride == 0) {
         // start/stop timestamps ride on the kernel's own dispatch packet: no extra stream commands
@@ -348,9 +362,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-        uint32_t scan_blocks = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;
-        if (scan_blocks < 1) scan_blocks = 1;
-        if (scan_blocks > REINA_MAX_SCAN_WAVES / SCAN_WAVES) scan_blocks = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
+        const uint32_t scan_blocks = scan_blocks_for(N, K);
         int ig = grid_for(N / 64 + 1, 256, 512) * 2;  // even: candidates / deferred lists
         if (K > 1 && ig > (int)(4096 / K)) ig = (int)(4096 / K) >= 2 ? ((int)(4096 / K) & ~1) : 2;
         hipLaunchKernelGGL(k_install, dim3(ig, K), dim3(256), 0, s, refs, dp, scan_blocks * SCAN_WAVES, scan_tiles);
