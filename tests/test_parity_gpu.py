@@ -124,11 +124,12 @@ def test_eager_iterate_equals_batched_run():
     assert np.array_equal(a.engine.read_counters(), b.engine.read_counters())
 
 
-def test_hus_full_population_150_days():
-    """BASELINE config 2 population: 1 685 983 agents, default scenario, first wave + saturated
-    beds/ICU + start of contact tracing"""
+def test_hus_full_population_full_year():
+    """BASELINE config 2 as benchmarked: 1 685 983 agents, default scenario, all 365 days (first wave,
+    saturated beds / ICU, contact tracing from day 118, the autumn wave, the b1.1.7 imports) --
+    per-day counter blocks and the final state bit-exact vs oracle B"""
     v = copy.deepcopy(VARIABLE_DEFAULTS)
-    _run_and_compare(v, datasets.get_population_for_area(), 0, 150, chunk=50)
+    _run_and_compare(v, datasets.get_population_for_area(), 0, 365, chunk=73)
 
 
 def test_ragged_population_sizes():
