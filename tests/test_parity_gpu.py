@@ -141,21 +141,13 @@ def test_ragged_population_sizes():
 
 
 def test_conservation_at_scale():
-    """size-independent properties on a 20M-agent synthetic population (no oracle run): every day
-    susceptible+infected+recovered+dead == N, all_infected == infected+recovered+dead,
-    hospitalized == in_ward+in_icu, sum(daily_contacts) == exposed_per_day"""
-    v = copy.deepcopy(VARIABLE_DEFAULTS)
-    S = 20_000_000 / 1685983
-    v.update(hospital_beds=int(2600 * S), icu_units=int(300 * S))
-    ivs = []
-    for iv in v['interventions']:
-        iv = list(iv)
-        if iv[0] in ('import-infections', 'import-infections-weekly'):
-            iv[2] = int(iv[2] * S)
-        ivs.append(iv)
-    ages = datasets.scaled_population(20_000_000)
-    ctx = simulation.make_context(v, age_counts=ages, seed=1, interventions=ivs)
-    hist = ctx.run(120)
+    """BASELINE configs[2] at full size (50 M agents, 365 days; no oracle run): size-independent
+    properties -- every day susceptible+infected+recovered+dead == N, all_infected ==
+    infected+recovered+dead, hospitalized == in_ward+in_icu, sum(daily_contacts) == exposed_per_day,
+    no problem flag; and determinism: the same seed gives the identical 365-day history twice."""
+    import bench
+    v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 50_000_000)
+    hist = simulation.make_context(v, age_counts=ages, seed=1).run(365)
     A = eng.MAX_AGES
     N = int(ages.sum())
     def tot(name):
@@ -166,8 +158,10 @@ def test_conservation_at_scale():
     assert np.all(tot('all_infected') == tot('infected') + tot('recovered') + tot('dead'))
     assert np.all(tot('hospitalized') == tot('in_ward') + tot('in_icu'))
     assert np.all(sc[:, eng.S_DAILY_CONTACTS:eng.S_DAILY_CONTACTS + 6].sum(axis=1) == sc[:, eng.S_EXPOSED_PER_DAY])
-    assert tot('all_infected')[-1] > 100000
+    assert tot('all_infected')[-1] > 5_000_000
     assert np.all(sc[:, eng.S_PROBLEM] == 0)
+    again = simulation.make_context(v, age_counts=ages, seed=1).run(365)
+    assert np.array_equal(hist, again)
 
 
 def test_sharded_population_two_shards_on_one_gpu():
