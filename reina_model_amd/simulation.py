@@ -131,27 +131,47 @@ def simulate_individuals(variables=None, step_callback=None, callback_day_interv
     return df, adf
 
 
-def _frames_from_history(ctx, hist, mobility_history, start_date, ms_per_day=0.0):
-    """(df, adf) of simulate_individuals from a recorded counter history[days, COUNTER_WORDS]."""
+def _frames_from_history(ctx, hist, mobility_history, start_date, ms_per_day=0.0, want_adf=True):
+    """(df, adf) of simulate_individuals from a recorded counter history[days, COUNTER_WORDS]; all
+    days at once (the per-day dict path, Context.state_from_counters, gives the same numbers -- checked
+    in tests/test_host_logic.py)."""
     import pandas as pd
     days = hist.shape[0]
+    A = _eng.MAX_AGES
     age_groups = ctx.age_group_labels
+    ngroups = len(age_groups)
     date_index = pd.date_range(start_date, periods=days)
     cols = POP_ATTRS + STATE_ATTRS + EXPOSURES_ATTRS + ['us_per_infected']
-    rows = []
-    ag_array = np.empty((days, len(POP_ATTRS), len(age_groups)), dtype='i')
-    for k in range(days):
-        s = ctx.state_from_counters(hist[k], mobility_factor=mobility_history[k])
-        for idx, attr in enumerate(POP_ATTRS):
-            ag_array[k, idx, :] = s[attr]
-        rec = {attr: s[attr].sum() for attr in POP_ATTRS}
-        for a in STATE_ATTRS:
-            rec[a] = s[a]
-        for place, nr in s['daily_contacts'].items():
-            rec['exposures_%s' % place] = nr
-        rec['us_per_infected'] = ms_per_day * 1000 / rec['infected'] if rec['infected'] else 0
-        rows.append(rec)
-    df = pd.DataFrame(rows, index=date_index, columns=cols)
+    # age -> report group sums as one matrix product per attribute: [days, nr_ages] @ [nr_ages, groups]
+    onehot = np.zeros((ctx.nr_ages, ngroups), dtype=np.int64)
+    onehot[np.arange(ctx.nr_ages), ctx.age_group_indices[:ctx.nr_ages]] = 1
+    ag_array = np.empty((days, len(POP_ATTRS), ngroups), dtype='i')
+    data = {}
+    for idx, attr in enumerate(POP_ATTRS):
+        ci = _eng.C_NAMES.index(attr)
+        per_age = hist[:, ci * A: ci * A + ctx.nr_ages].astype(np.int64)
+        ag_array[:, idx, :] = per_age @ onehot
+        data[attr] = ag_array[:, idx, :].sum(axis=1)
+    sc = hist[:, _eng.C_NR * A:].astype(np.int64)
+    infections, infectors = sc[:, _eng.S_TOTAL_INFECTIONS], sc[:, _eng.S_TOTAL_INFECTORS]
+    r = np.zeros(days, dtype=object)   # the reference's `r` is the int 0 until more than 5 infectors were seen
+    ok = infectors > 5
+    r[ok] = infections[ok] / infectors[ok]
+    r[~ok] = 0
+    data['exposed_per_day'] = sc[:, _eng.S_EXPOSED_PER_DAY]
+    data['available_hospital_beds'] = sc[:, _eng.S_AVAILABLE_BEDS]
+    data['available_icu_units'] = sc[:, _eng.S_AVAILABLE_ICU]
+    data['total_icu_units'] = sc[:, _eng.S_ICU_UNITS]
+    data['ct_cases_per_day'] = sc[:, _eng.S_CT_CASES_PER_DAY]
+    data['r'] = r
+    data['mobility_limitation'] = 1 - np.asarray(mobility_history[:days], dtype=np.float64)
+    for i, place in enumerate(model.PLACES):
+        data['exposures_%s' % place] = sc[:, _eng.S_DAILY_CONTACTS + i]
+    infected = data['infected'].astype(np.float64)
+    data['us_per_infected'] = np.where(infected > 0, ms_per_day * 1000 / np.where(infected > 0, infected, 1), 0)
+    df = pd.DataFrame(data, index=date_index, columns=cols)
+    if not want_adf:
+        return df, None
     adf = pd.DataFrame(
         ag_array.flatten(),
         index=pd.MultiIndex.from_product([date_index, POP_ATTRS, age_groups], names=['date', 'attr', 'age_group']),
@@ -229,7 +249,7 @@ def run_monte_carlo(scenario_name, seeds=range(1000), device='cuda:0', group_siz
         ms_per_day = (time.perf_counter() - t0) * 1000 / days / len(part)
         for m, sd in enumerate(part):
             df, _ = _frames_from_history(members[m], hist[m], plan['mobility_history'],
-                                         date.fromisoformat(v['start_date']), ms_per_day)
+                                         date.fromisoformat(v['start_date']), ms_per_day, want_adf=False)
             df['run'] = sd
             dfs.append(df)
         del members, planner

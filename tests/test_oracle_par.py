@@ -205,3 +205,27 @@ def test_in_stream_collective_hook_is_called_once_per_day():
     ha, hb = a.run(40), b.run(40)
     assert np.array_equal(ha, hb)
     assert len(calls) == 40 and all(c == (True, eng.PRESSURE_WORDS, 2, 0, 1234) for c in calls)
+
+
+def test_vectorised_frames_equal_the_per_day_path():
+    """simulation._frames_from_history (all days at once; the Monte-Carlo runner's path) gives the same
+    (df, adf) as simulate_individuals' per-day generate_state-style loop"""
+    import copy
+    import numpy as np
+    import par_backend
+    from datetime import date
+    from reina_model_amd import datasets, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=8, icu_units=2, simulation_days=120)
+    ages = datasets.scaled_population(8000)
+    df1, adf1 = simulation.simulate_individuals(v, engine_factory=par_backend.par_engine_factory, age_counts=ages)
+    ctx = simulation.make_context(v, age_counts=ages, engine_factory=par_backend.par_engine_factory)
+    hist = ctx.run(120)
+    df2, adf2 = simulation._frames_from_history(ctx, hist, ctx.mobility_history, date.fromisoformat(v['start_date']))
+    for col in df1.columns:
+        if col == 'us_per_infected':
+            continue
+        a, b = df1[col].values, df2[col].values
+        assert np.array_equal(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)), col
+    assert (adf1.values == adf2.values).all() and list(adf1.columns) == list(adf2.columns)
