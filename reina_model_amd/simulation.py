@@ -96,8 +96,13 @@ def simulate_individuals(variables=None, step_callback=None, callback_day_interv
     rows = []
     ag_array = np.empty((days, len(POP_ATTRS), len(age_groups)), dtype='i')
 
+    if step_callback is None:   # no progress reports wanted: one run, frames for all days at once
+        last = time.perf_counter()
+        hist = ctx.run(days)
+        return _frames_from_history(ctx, hist, ctx.mobility_history, start_date, (time.perf_counter() - last) * 1000 / days)
+
     done = 0
-    stretch = days if step_callback is None else max(1, int(callback_day_interval))
+    stretch = max(1, int(callback_day_interval))
     last = time.perf_counter()
     while done < days:
         n = min(stretch, days - done)
@@ -117,10 +122,9 @@ def simulate_individuals(variables=None, step_callback=None, callback_day_interv
             rec['us_per_infected'] = ms_per_day * 1000 / rec['infected'] if rec['infected'] else 0
             rows.append(rec)
         done += n
-        if step_callback is not None:
-            df = pd.DataFrame(rows, index=date_index[:done], columns=cols).reindex(date_index)
-            if not step_callback(df):
-                raise ExecutionInterrupted()
+        df = pd.DataFrame(rows, index=date_index[:done], columns=cols).reindex(date_index)
+        if not step_callback(df):
+            raise ExecutionInterrupted()
     df = pd.DataFrame(rows, index=date_index, columns=cols)
     adf = pd.DataFrame(
         ag_array.flatten(),

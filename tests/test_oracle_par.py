@@ -219,7 +219,11 @@ def test_vectorised_frames_equal_the_per_day_path():
     v = copy.deepcopy(VARIABLE_DEFAULTS)
     v.update(hospital_beds=8, icu_units=2, simulation_days=120)
     ages = datasets.scaled_population(8000)
-    df1, adf1 = simulation.simulate_individuals(v, engine_factory=par_backend.par_engine_factory, age_counts=ages)
+    seen = []
+    df1, adf1 = simulation.simulate_individuals(v, engine_factory=par_backend.par_engine_factory, age_counts=ages,
+                                               step_callback=lambda df: seen.append(len(df.dropna())) or True,
+                                               callback_day_interval=40)   # the per-day path
+    assert seen == [40, 80, 120]
     ctx = simulation.make_context(v, age_counts=ages, engine_factory=par_backend.par_engine_factory)
     hist = ctx.run(120)
     df2, adf2 = simulation._frames_from_history(ctx, hist, ctx.mobility_history, date.fromisoformat(v['start_date']))
