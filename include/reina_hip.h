@@ -35,6 +35,7 @@ extern "C" {
 #define REINA_MAX_SHARDS 16     /* ranks an agent population can be sharded over */
 #define REINA_MAX_RANGES 32     /* distinct contact age ranges (reference: 15) */
 #define REINA_PRESSURE_WORDS (REINA_MAX_SHARDS * REINA_MAX_RANGES * REINA_MAX_VARIANTS)
+#define REINA_MIRROR_CELLS (REINA_MAX_RANGES * REINA_MAX_VARIANTS)
 
 /* error codes */
 #define REINA_OK 0
@@ -179,6 +180,9 @@ typedef struct {
                                  a day-tagged hash sample of this shard's OUTGOING cross-shard attempts,
                                  from which an incoming infection takes a local stand-in infector
                                  ("mirror attribution", reina_model_amd/sharding.py) */
+    uint32_t *mirror_meta;    /* [2 * REINA_MIRROR_CELLS] sharded runs only: per cell the number of slots in use
+                                 today (a power of two, sized from yesterday's traffic so the table stays
+                                 dense and a lookup takes a handful of probes) and day + 1 of its last entry */
     uint32_t *work_counts;    /* [5 * REINA_MAX_SCAN_WAVES] entries per scanning-wave slice of the per-slice
                                  lists (no global append counters): exposure candidates, symptom onsets,
                                  hospital events, bookkeeping (written by the scan) and infection

@@ -123,6 +123,10 @@ int par_init_state(Par *e, int32_t beds, int32_t icu, void *stream) {
     if (e->cfg.n_shards > 1)
         for (size_t k = 0; k < (size_t)REINA_MAX_RANGES * REINA_MAX_VARIANTS * e->cfg.mirror_slots; k++)
             e->buf.mirror[k] = ~0ull;
+    for (uint32_t c = 0; c < REINA_MIRROR_CELLS; c++) {   /* smallest tables, no entries yet */
+        e->buf.mirror_meta[c] = e->cfg.mirror_slots < RP_MIRROR_MIN_SLOTS ? e->cfg.mirror_slots : RP_MIRROR_MIN_SLOTS;
+        e->buf.mirror_meta[REINA_MIRROR_CELLS + c] = 0;
+    }
     for (uint32_t k = 0; k < (N + 31) / 32 + 1; k++) e->buf.sus_bits[k] = 0;
     for (uint32_t i = 0; i < N; i++) e->buf.sus_bits[i >> 5] |= 1u << (i & 31);
     memset(e->buf.counters, 0, sizeof(int32_t) * REINA_COUNTER_WORDS);
@@ -809,10 +813,12 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
                 /* mirror table: keep the smallest (tie-break, src) per slot, tagged with today */
                 {
                     rp_u4 hm = rp_philox(e->k0, e->k1, src, dp->day, RP_P_MIRROR, (uint32_t)c);
-                    uint32_t S = e->cfg.mirror_slots;
-                    uint64_t *slot = e->buf.mirror + ((size_t)(range_id * REINA_MAX_VARIANTS + (uint32_t)v)) * S + (hm.v[0] & (S - 1));
+                    uint32_t S = e->cfg.mirror_slots, cell = range_id * REINA_MAX_VARIANTS + (uint32_t)v;
+                    uint32_t eff = e->buf.mirror_meta[cell];   /* slots of this cell in use today */
+                    uint64_t *slot = e->buf.mirror + (size_t)cell * S + (hm.v[0] & (eff - 1));
                     uint64_t ent = rp_order_key(dp->day, hm.v[1] >> 12, src);
                     if (ent < *slot) *slot = ent;
+                    e->buf.mirror_meta[REINA_MIRROR_CELLS + cell] = dp->day + 1;
                 }
                 continue;
             }
@@ -869,14 +875,16 @@ static void run_remote(Par *e, const reina_day_t *dp) {
                 uint32_t src = RP_REMOTE_SRC | idx;
                 {
                     uint32_t S = e->cfg.mirror_slots;
-                    uint32_t probes = S < RP_MIRROR_PROBES ? S : RP_MIRROR_PROBES;
                     int found = 0;
                     for (uint32_t dv = 0; dv < e->cfg.nr_variants && !found; dv++)
                         for (uint32_t dr = 0; dr < e->n_ranges && !found; dr++) {
                             uint32_t cell = ((rg + dr) % e->n_ranges) * REINA_MAX_VARIANTS + (v + dv) % e->cfg.nr_variants;
+                            if (e->buf.mirror_meta[REINA_MIRROR_CELLS + cell] != dp->day + 1) continue;   /* nothing today */
+                            const uint32_t eff = e->buf.mirror_meta[cell];
+                            const uint32_t probes = eff < RP_MIRROR_PROBES ? eff : RP_MIRROR_PROBES;
                             const uint64_t *tab = e->buf.mirror + (size_t)cell * S;
                             for (uint32_t j = 0; j < probes; j++) {
-                                uint64_t ent = tab[(r.v[3] + j) & (S - 1)];
+                                uint64_t ent = tab[(r.v[3] + j) & (eff - 1)];
                                 if ((ent >> 52) == ((4095u - dp->day) & 0xFFFu)) {
                                     src = (uint32_t)ent;
                                     found = 1;
@@ -909,6 +917,20 @@ static void run_install(Par *e, const reina_day_t *dp) {
         int32_t src = (cd[1] & RP_REMOTE_SRC) ? -1 : (int32_t)cd[1];
         install_infection(e, cd[0], dp->day, cd[2], src, 0, dp->testing_mode);
     }
+    /* tomorrow's mirror-table sizes: about twice this shard's share of today's cross-shard attempts of
+     * the cell (pressure holds the sums over all shards by now), a power of two in [8, mirror_slots] */
+    if (e->cfg.n_shards > 1)
+        for (uint32_t cell = 0; cell < REINA_MIRROR_CELLS; cell++) {
+            uint32_t tot = 0;
+            for (uint32_t dest = 0; dest < e->cfg.n_shards; dest++) {
+                int n = e->buf.pressure[dest * REINA_MIRROR_CELLS + cell];
+                tot += n > 0 ? (uint32_t)n : 0u;
+            }
+            const uint32_t want = 2u * ((tot + e->cfg.n_shards - 1) / e->cfg.n_shards);
+            uint32_t eff = e->cfg.mirror_slots < RP_MIRROR_MIN_SLOTS ? e->cfg.mirror_slots : RP_MIRROR_MIN_SLOTS;
+            while (eff < want && eff < e->cfg.mirror_slots) eff <<= 1;
+            e->buf.mirror_meta[cell] = eff;
+        }
 }
 
 /* Context.iterate (main.pyx:2011-2018) in the parallel formulation, first half */

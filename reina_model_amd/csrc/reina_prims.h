@@ -254,6 +254,7 @@ RP_HD uint64_t rp_shard_seed(uint64_t seed, uint32_t rank) {
 }
 // candidate "source id" of an infection realised from cross-shard pressure (no local infector)
 #define RP_REMOTE_SRC 0x80000000u
-#define RP_MIRROR_PROBES 1024u
+#define RP_MIRROR_PROBES 16u      // probes per cell of the mirror table (tables are kept >= ~40 % full)
+#define RP_MIRROR_MIN_SLOTS 8u    // smallest table: fully scanned by one lookup
 
 #endif  // REINA_PRIMS_H

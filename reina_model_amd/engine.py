@@ -89,7 +89,7 @@ class ContactTablesABI(ctypes.Structure):
 
 BUFFER_FIELDS = ('hot', 'infector', 'n_infected', 'onset_days', 'vacc_day', 'first_infectee',
                  'next_sibling', 'claim', 'counters', 'control', 'work_items', 'candidates',
-                 'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'work_counts', 'scan_lists', 'sus_bits')
+                 'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'mirror_meta', 'work_counts', 'scan_lists', 'sus_bits')
 
 
 class Buffers(ctypes.Structure):
@@ -229,6 +229,7 @@ class Engine:
             level1=a.zeros(config.max_queue, np.uint32), hosp_events=a.zeros(MAX_HOSP_EVENTS, np.uint64),
             pressure=a.zeros(PRESSURE_WORDS, np.int32),
             mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 32, np.uint64),
+            mirror_meta=a.zeros(2 * MAX_RANGES * MAX_VARIANTS, np.uint32),
             work_counts=a.zeros(5 * MAX_SCAN_WAVES, np.uint32),
             scan_lists=a.zeros(4 * config.max_work_items, np.uint32),
             sus_bits=a.zeros((n + 31) // 32 + 1, np.uint32),
