@@ -60,8 +60,8 @@ static int grid_for(uint32_t n_items, int threads, int max_blocks) {
 
 static size_t take_event(reina_engine *e) {
     if (e->ev_used == e->ev_pool.size()) {
-        hipEvent_t ev;
-        hipEventCreate(&ev);
+        hipEvent_t ev = nullptr;
+        (void)hipEventCreate(&ev);   // (a failed creation surfaces as an invalid-handle error at the launch)
         e->ev_pool.push_back(ev);
     }
     return e->ev_used++;
@@ -170,15 +170,16 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
 
 int reina_destroy(reina_engine_t *e) {
     if (!e) return REINA_E_INVALID;
-    for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    // teardown: nothing useful can be done about a failing free
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (size_t k = 0; k < e->stage.size(); k++) {
-        hipEventSynchronize(e->stage_ev[k]);
-        hipEventDestroy(e->stage_ev[k]);
-        hipHostFree(e->stage[k]);
+        (void)hipEventSynchronize(e->stage_ev[k]);
+        (void)hipEventDestroy(e->stage_ev[k]);
+        (void)hipHostFree(e->stage[k]);
     }
-    hipFree(e->d_params);
-    hipFree(e->d_tables);
-    hipFree(e->d_ref);
+    (void)hipFree(e->d_params);
+    (void)hipFree(e->d_tables);
+    (void)hipFree(e->d_ref);
     delete e;
     return REINA_OK;
 }
@@ -457,7 +458,7 @@ int reina_group_create(reina_engine_t **engines, uint32_t n, reina_group_t **out
 
 int reina_group_destroy(reina_group_t *g) {
     if (!g) return REINA_E_INVALID;
-    hipFree(g->d_refs);
+    (void)hipFree(g->d_refs);
     delete g;
     return REINA_OK;
 }
