@@ -360,16 +360,18 @@ def test_sharded_population_at_config3_scale():
     assert tot('all_infected') > 5_000_000
 
 
-def test_large_tracing_queues():
-    """An unmitigated wave in 2.5 M agents with contact tracing on: thousands of detections a day, so
-    the level-0 tracing pass spans several workgroups and the level-1 list is walked by whichever
-    finishes last (the folded path of k_open, populations below 8 M) -- bit-exact vs oracle B."""
+@pytest.mark.parametrize('total,days', [(2_500_000, 70), (9_000_000, 45)])
+def test_large_tracing_queues(total, days):
+    """An unmitigated wave with contact tracing on: thousands of detections a day, so the level-0
+    tracing pass spans several workgroups; below 8 M agents the level-1 list is walked by whichever
+    of them finishes last (folded path of k_open), above it by a launch of its own -- both bit-exact
+    vs oracle B."""
     v = copy.deepcopy(VARIABLE_DEFAULTS)
     v.update(hospital_beds=3000, icu_units=300)
     ivs = [['import-infections', '2020-02-19', 3000], ['import-infections', '2020-02-25', 2000, 'b1.1.7'],
            ['test-all-with-symptoms', '2020-02-20'], ['test-with-contact-tracing', '2020-03-05', 70],
            ['import-infections-weekly', '2020-03-01', 700, 30]]
-    ages = datasets.scaled_population(2_500_000)
-    gpu, cpu = _run_and_compare(v, ages, 11, 70, interventions=ivs, chunk=35)
+    ages = datasets.scaled_population(total)
+    gpu, cpu = _run_and_compare(v, ages, 11, days, interventions=ivs, chunk=35)
     c = gpu.per_age_counters()
-    assert c['all_detected'].sum() > 100_000   # >> 1024 queue entries on the busy days
+    assert c['all_detected'].sum() > 50_000   # >> 1024 queue entries on the busy days
