@@ -122,3 +122,12 @@ def test_sample_draws_match_reference():
     ctx = so.make_context(copy.deepcopy(VARIABLE_DEFAULTS), ages, 77, interventions=[])
     assert np.array_equal(ctx.sample('contacts_per_day', 33), z['chain77|contacts_per_day|33'])
     assert np.array_equal(ctx.sample('incubation_period', 33), z['chain77|incubation_period|33'])
+
+
+def test_cli_day_table_matches_the_recorded_run(capsys):
+    """BASELINE configs[0] plumbing: `python -m oracle.cli --check` prints the reference's day table from
+    oracle A and verifies every printed day against the recorded cythonsim run"""
+    from oracle import cli
+    cli.main(['--days', '25', '--seed', '1', '--check'])
+    out = capsys.readouterr().out
+    assert 'all 25 days identical' in out and out.count('\n') >= 27
