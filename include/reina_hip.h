@@ -80,6 +80,7 @@ enum {
     REINA_L_CONTACTS, REINA_L_HOSP_ADMIT, REINA_L_ICU_ADMIT,
     REINA_L_DAY_OPEN,                                   /* day + 1 once that day's snapshot / zeroing is done */
     REINA_L_TRACE_DONE,                                 /* level-0 tracing workgroups finished today (folded level 1) */
+    REINA_L_CAND_OVF,                                   /* candidate records that did not fit their slice's region today */
     REINA_L_VACC_CURSOR = 16,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_NR = 32
 };

@@ -152,6 +152,14 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     }
     e->h_params.max_work_items = cfg->max_work_items;
     e->h_params.max_candidates = cfg->max_candidates;
+    {   // the space above the per-wave regions: half (at most 2^20 records) for records that overflow a wave's
+        // region, the rest for the cross-shard candidates of k_remote
+        const uint32_t extra = cfg->max_candidates > cfg->max_work_items ? cfg->max_candidates - cfg->max_work_items : 0u;
+        uint32_t ovf = extra / 2;
+        if (ovf > (1u << 20)) ovf = 1u << 20;
+        e->h_params.cand_ovf_cap = ovf;
+        e->h_params.cand_ovf_base = cfg->max_candidates - ovf;
+    }
     e->h_params.max_queue = cfg->max_queue;
     HIP_CHECK(hipMalloc(&e->d_params, sizeof(DevParams)));
     HIP_CHECK(hipMalloc(&e->d_tables, sizeof(Tables)));

@@ -266,8 +266,9 @@ class Context:
         cfg.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
         cfg.max_work_items = total + 1024
         # candidate records: one region per scanning wave (total) + the region k_remote fills with one
-        # record per incoming cross-shard attempt (a few % of the shard per day at an epidemic peak)
-        cfg.max_candidates = total + (max(1024 * 1024, total // 2) if self.n_shards > 1 else 1024 * 1024)
+        # record per incoming cross-shard attempt (a few % of the shard per day at an epidemic peak) + an
+        # overflow region of the same size (at most 2^20 records) for waves with more hits than agents
+        cfg.max_candidates = total + 2 * (max(1024 * 1024, total // 2) if self.n_shards > 1 else 1024 * 1024)
         cfg.max_queue = total + 64
         cfg.n_shards = self.n_shards
         cfg.shard_rank = self.shard_rank

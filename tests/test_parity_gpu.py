@@ -375,3 +375,21 @@ def test_large_tracing_queues(total, days):
     gpu, cpu = _run_and_compare(v, ages, 11, days, interventions=ivs, chunk=35)
     c = gpu.per_age_counters()
     assert c['all_detected'].sum() > 50_000   # >> 1024 queue entries on the busy days
+
+
+def test_three_variants():
+    """wild type + two variants with their own multipliers and durations, imported by date and through
+    the weekly shares (one 'variant_<name>' share per variant, common/interventions.py:300-323)"""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=15, icu_units=3)
+    v['variants'] = [{'name': 'b1.1.7', 'infectiousness_multiplier': 1.3},
+                     {'name': 'p.1', 'infectiousness_multiplier': 1.6, 'mean_incubation_duration': 4.0,
+                      'p_asymptomatic_infection': 50.0}]
+    ivs = [['import-infections', '2020-02-19', 40], ['import-infections', '2020-02-25', 30, 'b1.1.7'],
+           ['import-infections', '2020-03-01', 30, 'p.1'], ['test-all-with-symptoms', '2020-02-22'],
+           ['import-infections-weekly', '2020-03-05', 70, 30, 20], ['test-with-contact-tracing', '2020-03-20', 60],
+           ['limit-mobility', '2020-03-25', 40], ['import-infections-weekly', '2020-04-20', 35, 0, 100]]
+    gpu, cpu = _run_and_compare(v, datasets.scaled_population(50000), 17, 130, interventions=ivs, chunk=65)
+    s = gpu.generate_state()
+    assert set(s['infected_by_variant']) == {'wild-type', 'b1.1.7', 'p.1'}
+    assert gpu.per_age_counters()['all_infected'].sum() > 3000
