@@ -295,9 +295,12 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
     for (uint32_t b = 0; b < dp->n_import_batches; b++)
         if ((int)dp->import_batches[b].pre_init == pre_init)
             for (uint32_t k = 0; k < dp->import_batches[b].count; k++) variant[n++] = dp->import_batches[b].variant;
+    /* imports are worked off in chunks of 16384 (the HIP kernel's LDS bookkeeping), rounds per chunk */
+    for (uint32_t c0 = 0; c0 < total; c0 += 16384u) {
+    const uint32_t c1 = total - c0 < 16384u ? total : c0 + 16384u;
     for (uint32_t round = 0; round < 10; round++) {
         uint32_t proposals = 0;
-        for (uint32_t j = 0; j < total; j++) {
+        for (uint32_t j = c0; j < c1; j++) {
             target[j] = 0xFFFFFFFFu;
             if (next_try[j] == 255) continue;
             uint32_t k = next_try[j];
@@ -312,12 +315,12 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
             if (target[j] != 0xFFFFFFFFu) proposals++;
         }
         if (!proposals) break;
-        for (uint32_t j = 0; j < total; j++) {
+        for (uint32_t j = c0; j < c1; j++) {
             if (target[j] == 0xFFFFFFFFu) continue;
             uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
             if (key < e->buf.claim[target[j]]) e->buf.claim[target[j]] = key;
         }
-        for (uint32_t j = 0; j < total; j++) {
+        for (uint32_t j = c0; j < c1; j++) {
             if (target[j] == 0xFFFFFFFFu) continue;
             uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
             if (e->buf.claim[target[j]] == key) {
@@ -325,6 +328,7 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
                 next_try[j] = 255;
             }
         }
+    }
     }
     for (uint32_t j = 0; j < total; j++)
         if (next_try[j] != 255) SC(e, REINA_S_UNABLE_TO_IMPORT) += 1;

@@ -393,3 +393,14 @@ def test_three_variants():
     s = gpu.generate_state()
     assert set(s['infected_by_variant']) == {'wild-type', 'b1.1.7', 'p.1'}
     assert gpu.per_age_counters()['all_infected'].sum() > 3000
+
+
+def test_more_imports_in_a_day_than_one_chunk():
+    """40 000 + 9 000 infections imported on single days into 3 M agents (the import placement works in
+    chunks of 16 384), plus a big weekly flow -- bit-exact vs oracle B"""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=4000, icu_units=500)
+    ivs = [['import-infections', '2020-02-19', 40000], ['import-infections', '2020-02-21', 9000, 'b1.1.7'],
+           ['import-infections-weekly', '2020-02-24', 150000, 50], ['test-all-with-symptoms', '2020-02-25']]
+    gpu, cpu = _run_and_compare(v, datasets.scaled_population(3_000_000), 5, 25, interventions=ivs, chunk=25)
+    assert gpu.per_age_counters()['all_infected'].sum() > 300_000
