@@ -404,3 +404,26 @@ def test_more_imports_in_a_day_than_one_chunk():
            ['import-infections-weekly', '2020-02-24', 150000, 50], ['test-all-with-symptoms', '2020-02-25']]
     gpu, cpu = _run_and_compare(v, datasets.scaled_population(3_000_000), 5, 25, interventions=ivs, chunk=25)
     assert gpu.per_age_counters()['all_infected'].sum() > 300_000
+
+
+@pytest.mark.parametrize('case', range(10))
+def test_extreme_random_scenarios(case):
+    """Small populations driven hard: imports of the order of the population (placement failures,
+    susceptibles running out), infectiousness multipliers up to 3, no beds, contact tracing with full
+    efficiency, everything at once -- HIP == oracle B bit for bit (or the identical failure)."""
+    rng = np.random.default_rng(7000 + case)
+    v, ages, days, ivs, ipc = _random_scenario(rng)
+    total = int(rng.integers(600, 6000))
+    ages = datasets.scaled_population(total)
+    v['infectiousness_multiplier'] = float(rng.uniform(1.0, 3.0))
+    v['variants'] = [{'name': 'b1.1.7', 'infectiousness_multiplier': float(rng.uniform(1.5, 3.0))}]
+    v['hospital_beds'] = int(rng.integers(0, 3))
+    v['icu_units'] = int(rng.integers(0, 2))
+    from datetime import date, timedelta
+    d0 = date.fromisoformat(v['start_date'])
+    ivs = list(ivs) + [['import-infections', (d0 + timedelta(days=int(rng.integers(0, 20)))).isoformat(), int(total * rng.uniform(0.2, 1.5))],
+                       ['import-infections-weekly', (d0 + timedelta(days=int(rng.integers(0, 30)))).isoformat(), int(total * rng.uniform(0.1, 2.0)), int(rng.integers(0, 101))],
+                       ['test-with-contact-tracing', (d0 + timedelta(days=int(rng.integers(0, 30)))).isoformat(), 100]]
+    if ipc is not None:
+        ipc = {k: min(val, total // 12) for k, val in ipc.items()}
+    _run_and_compare(v, ages, int(rng.integers(0, 2 ** 31)), min(days, 90), interventions=ivs, chunk=30, ipc=ipc)
