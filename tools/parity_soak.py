@@ -1,0 +1,31 @@
+"""One-off soak: many more randomised scenarios than the suite runs (HIP vs oracle B, bit for bit)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import test_parity_gpu as T
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+bad = 0
+t0 = time.time()
+for case in range(n):
+    for kind, seed0 in (('random', 100000), ('extreme', 200000)):
+        rng = np.random.default_rng(seed0 + case)
+        v, ages, days, ivs, ipc = T._random_scenario(rng)
+        try:
+            if kind == 'extreme':
+                total = int(rng.integers(600, 6000))
+                ages = T.datasets.scaled_population(total)
+                v['infectiousness_multiplier'] = float(rng.uniform(1.0, 3.0))
+                v['hospital_beds'] = int(rng.integers(0, 3)); v['icu_units'] = int(rng.integers(0, 2))
+                from datetime import date, timedelta
+                d0 = date.fromisoformat(v['start_date'])
+                ivs = list(ivs) + [['import-infections', (d0 + timedelta(days=int(rng.integers(0, 20)))).isoformat(), int(total * rng.uniform(0.2, 1.5))],
+                                   ['test-with-contact-tracing', (d0 + timedelta(days=int(rng.integers(0, 30)))).isoformat(), 100]]
+                if ipc is not None:
+                    ipc = {k: min(val, total // 12) for k, val in ipc.items()}
+                days = min(days, 90)
+            T._run_and_compare(v, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
+        except AssertionError as e:
+            bad += 1
+            print('MISMATCH %s case %d: %s' % (kind, case, str(e)[:300]), flush=True)
+print('soak: %d scenarios, %d mismatches, %.0f s' % (2 * n, bad, time.time() - t0))
