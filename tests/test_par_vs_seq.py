@@ -158,3 +158,33 @@ def test_hip_engine_against_the_recorded_reference_runs_at_hus_scale():
             worst = max(worst, abs(g.mean() - r.mean()) / tol)
             assert abs(g.mean() - r.mean()) <= tol, (d, n, g.mean(), r.mean(), tol)
     print('worst |diff|/tol = %.2f' % worst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family,n_ref', [('mini_kitchen', 6), ('mini_default', 8), ('mini_imports', 4), ('mini_initial', 4)])
+def test_hip_engine_against_the_recorded_mini_runs(family, n_ref):
+    """Every intervention type against the REAL reference: 64 GPU seeds vs the recorded cythonsim runs
+    of the same scenario (kitchen sink: vaccination, new beds / ICU, masks, variant imports, tracing;
+    default interventions; imports only; initial population condition), 13 quantities every 25th day,
+    tolerance 4 * sqrt(var_gpu/64 + var_ref/n_ref) + 0.5 % + 1."""
+    from golden_util import load_run, variables_for
+    from reina_model_amd import engine as eng, ensemble
+    runs = [load_run('%s_s%d' % (family, k)) for k in range(n_ref)]
+    meta = runs[0][1]
+    ref = np.array([z['pop'].sum(axis=2) for z, _ in runs]).astype(np.float64)   # [n_ref, days, 13]
+    v = variables_for(meta)
+    ages = np.asarray(meta['age_counts'])
+    members = []
+    from reina_model_amd import simulation
+    plan_ctx = simulation.make_context(v, age_counts=ages, seed=0, interventions=meta['interventions'], ipc=meta.get('ipc'))
+    plan = plan_ctx.make_plan(meta['days'])
+    members = [simulation.make_context(v, age_counts=ages, seed=31000 + s, interventions=meta['interventions'], ipc=meta.get('ipc'))
+               for s in range(64)]
+    hist = ensemble.run_group_plan(members, plan)
+    A = eng.MAX_AGES
+    for d in range(25, meta['days'], 25):
+        for i, n in enumerate(meta['pop13']):
+            g = hist[:, d, eng.C_NAMES.index(n) * A:(eng.C_NAMES.index(n) + 1) * A].sum(axis=1).astype(np.float64)
+            r = ref[:, d, i]
+            tol = 4.0 * np.sqrt(g.var(ddof=1) / len(g) + r.var(ddof=1) / len(r)) + 0.005 * abs(r.mean()) + 1.0
+            assert abs(g.mean() - r.mean()) <= tol, (family, d, n, g.mean(), r.mean(), tol)
