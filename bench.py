@@ -255,6 +255,7 @@ def ensemble_line(seeds, days, device):
 
 
 def main():
+    t_process = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=365)
@@ -385,6 +386,10 @@ def main():
                 res = cpu_all.run()
                 if res is not None:
                     out['cpu_baseline']['all_cores'] = res
+        out['timing'] = {
+            'timed_region_s': round(dt, 6), 'process_wall_s': round(time.perf_counter() - t_process, 2),
+            'note': 'the process also builds contexts, runs untimed preheat simulations, the extra 50 M / ensemble '
+                    'configurations and the CPU baselines; value = agents x steps / timed_region_s'}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
