@@ -36,6 +36,11 @@ extern "C" {
 #define REINA_MAX_RANGES 32     /* distinct contact age ranges (reference: 15) */
 #define REINA_PRESSURE_WORDS (REINA_MAX_SHARDS * REINA_MAX_RANGES * REINA_MAX_VARIANTS)
 #define REINA_MIRROR_CELLS (REINA_MAX_RANGES * REINA_MAX_VARIANTS)
+/* sharded populations: the pressure words of contact range REINA_MAX_RANGES - 1 (never a real range: a
+ * sharded engine accepts at most REINA_MAX_RANGES - 1) carry each shard's free beds / free ICU units
+ * through the same all-reduce, from which the free capacity is re-divided every evening */
+#define REINA_PRESSURE_FREE_BEDS(rank) (((rank) * REINA_MAX_RANGES + (REINA_MAX_RANGES - 1)) * REINA_MAX_VARIANTS)
+#define REINA_PRESSURE_FREE_ICU(rank) (REINA_PRESSURE_FREE_BEDS(rank) + 1)
 
 /* error codes */
 #define REINA_OK 0

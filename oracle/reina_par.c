@@ -584,7 +584,17 @@ static int dies_in_hospital(Par *e, uint32_t i, uint32_t day, int sev, int v, in
 
 /* person_hospitalize / transfer_to_icu / release_from_hospital (main.pyx:321-367) +
  * HealthcareSystem bed accounting (:617-651), in priority order when capacity can bind */
+static void run_hospital_events(Par *e, const reina_day_t *dp);
+
 static void run_hospital(Par *e, const reina_day_t *dp) {
+    run_hospital_events(e, dp);
+    if (e->cfg.n_shards > 1) {   /* this shard's free capacity travels with the pressure all-reduce */
+        e->buf.pressure[REINA_PRESSURE_FREE_BEDS(e->cfg.shard_rank)] = SC(e, REINA_S_AVAILABLE_BEDS);
+        e->buf.pressure[REINA_PRESSURE_FREE_ICU(e->cfg.shard_rank)] = SC(e, REINA_S_AVAILABLE_ICU);
+    }
+}
+
+static void run_hospital_events(Par *e, const reina_day_t *dp) {
     int M = CTL(e, REINA_L_HOSP);
     if (!M) return;
     int b = SC(e, REINA_S_AVAILABLE_BEDS), c = SC(e, REINA_S_AVAILABLE_ICU);
@@ -920,6 +930,18 @@ static void run_install(Par *e, const reina_day_t *dp) {
         if (RH_STATE(e->buf.hot[cd[0]]) != RS_SUSCEPTIBLE) continue; /* duplicate record of the winner */
         int32_t src = (cd[1] & RP_REMOTE_SRC) ? -1 : (int32_t)cd[1];
         install_infection(e, cd[0], dp->day, cd[2], src, 0, dp->testing_mode);
+    }
+    /* the free beds / ICU units of all shards are pooled and re-divided for tomorrow (a shard whose share
+     * is exhausted gets part of what the others have free; totals are conserved) */
+    if (e->cfg.n_shards > 1) {
+        int64_t fb = 0, fc = 0;
+        for (uint32_t r = 0; r < e->cfg.n_shards; r++) {
+            fb += e->buf.pressure[REINA_PRESSURE_FREE_BEDS(r)];
+            fc += e->buf.pressure[REINA_PRESSURE_FREE_ICU(r)];
+        }
+        const int64_t G = e->cfg.n_shards, rk = e->cfg.shard_rank;
+        if (fb >= 0) SC(e, REINA_S_AVAILABLE_BEDS) = (int32_t)(fb / G + (rk < fb % G ? 1 : 0));
+        if (fc >= 0) SC(e, REINA_S_AVAILABLE_ICU) = (int32_t)(fc / G + (rk < fc % G ? 1 : 0));
     }
     /* tomorrow's mirror-table sizes: about twice this shard's share of today's cross-shard attempts of
      * the cell (pressure holds the sums over all shards by now), a power of two in [8, mirror_slots] */

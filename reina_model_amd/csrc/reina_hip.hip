@@ -231,6 +231,10 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     if (!e || !t) return REINA_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t A = e->cfg.nr_ages;
+    if (e->cfg.n_shards > 1 && t->n_ranges >= REINA_MAX_RANGES) {
+        g_last_error = "a sharded engine takes at most REINA_MAX_RANGES - 1 contact ranges (the last range's pressure words carry free capacity)";
+        return REINA_E_INVALID;
+    }
     std::memcpy(e->h_params.nrc, t->nr_contacts_by_age, sizeof(float) * A);
     std::memcpy(e->h_params.tcount, t->count, sizeof(int32_t) * A);
     std::memcpy(e->h_params.mask_p, t->mask_p, sizeof(float) * A * 8);

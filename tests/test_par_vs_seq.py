@@ -91,9 +91,10 @@ def test_sharded_formulation_matches_sequential_oracle_statistically(G):
                 out[d, k] = c[i * A:(i + 1) * A].sum()
             sharding.step_shards_together(ctxs)
         runs.append(out)
-    # the documented deviation of partitioned capacity, visible only in this corner: 35 ICU units split 8
-    # ways are 4-5 per shard and cannot all be kept occupied while the undivided pool is saturated (8
-    # shards: 26-27 vs 33 occupied); at scenario scale (hundreds of units per shard) the pools fill alike
+    # the documented deviation of partitioned capacity, visible only in this corner: 35 ICU units over 8
+    # shards are 4-5 per shard; the free units are pooled and re-divided every evening, but within a day a
+    # shard can still run dry while others have units free (8 shards: 28 vs 33 occupied at saturation); at
+    # scenario scale (hundreds of units per shard) the pools fill alike
     skip = (lambda d, a, ref_mean: a == 'in_icu' and ref_mean > 0.8 * v['icu_units']) if G == 8 else None
     _check(np.array(runs), z, me.ATTRS, skip)
 
