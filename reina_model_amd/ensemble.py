@@ -52,8 +52,28 @@ def run_group_plan(contexts, plan, record_history=True):
     return out
 
 
+def run_ensemble_distributed(variables, seeds, days, group=None, concurrent=64, **kw):
+    """BASELINE config 5: an ensemble over the GPUs of a node.  Replicas only -- rank r of the
+    torch.distributed group runs seeds[r::world] as engine groups on its own GPU, no data-path
+    collective; the histories are gathered on rank 0 (returned there in seed order, None elsewhere)."""
+    import torch.distributed as dist
+    seeds = list(seeds)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = seeds[rank::world]
+    hist = run_ensemble(variables, mine, days, concurrent=concurrent, **kw) if mine else None
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((mine, hist), parts, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if rank != 0:
+        return None
+    by_seed = {}
+    for sds, h in parts:
+        for k, sd in enumerate(sds):
+            by_seed[sd] = h[k]
+    return np.stack([by_seed[sd] for sd in seeds])
+
+
 def run_ensemble(variables, seeds, days, age_counts=None, device='cuda:0', threads=8, concurrent=None,
-                 interventions=None, batched=True):
+                 interventions=None, batched=True, engine_factory=None):
     """Run one simulation per seed for `days` days. Returns history[len(seeds), days, COUNTER_WORDS]
     (row d = counters before day d, as Context.run). `concurrent` bounds how many members hold HBM
     state at once (default: all)."""
@@ -62,13 +82,13 @@ def run_ensemble(variables, seeds, days, age_counts=None, device='cuda:0', threa
     concurrent = len(seeds) if concurrent is None else max(1, int(concurrent))
     if batched:
         planner = simulation.make_context(variables, age_counts=age_counts, seed=seeds[0], device=device,
-                                          interventions=interventions)
+                                          interventions=interventions, engine_factory=engine_factory)
         plan = planner.make_plan(days)
         del planner
         outs = []
         for start in range(0, len(seeds), concurrent):
             ctxs = [simulation.make_context(variables, age_counts=age_counts, seed=sd, device=device,
-                                            interventions=interventions)
+                                            interventions=interventions, engine_factory=engine_factory)
                     for sd in seeds[start:start + concurrent]]
             outs.append(run_group_plan(ctxs, plan))
             del ctxs

@@ -39,6 +39,21 @@ def main():
     if rank == 0:
         print('direct_rccl=%s' % (comm.direct is not None), flush=True)
     ctx = simulation.make_context(v, age_counts=ages, seed=21, engine_factory=factory, device=device, comm=comm)
+    if len(sys.argv) > 4 and sys.argv[4] == 'ensemble':
+        # config 5 shape: seeds partitioned over the ranks, gathered on rank 0
+        from reina_model_amd import ensemble
+        seeds = list(range(40, 47))
+        ens = ensemble.run_ensemble_distributed(v, seeds, days, age_counts=ages, engine_factory=factory, device=device)
+        if rank == 0:
+            for k, sd in enumerate(seeds):
+                one = simulation.make_context(v, age_counts=ages, seed=sd, engine_factory=par_backend.par_engine_factory).run(days)
+                assert np.array_equal(ens[k], one), 'ensemble member (seed %d) differs from its single run' % sd
+            print('ENSEMBLE_OK world=%d members=%d' % (world, len(seeds)), flush=True)
+        else:
+            assert ens is None
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     hist = ctx.run(days)
     final = ctx.generate_state()
     if rank == 0:

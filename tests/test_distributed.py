@@ -18,10 +18,10 @@ def _free_port():
     return p
 
 
-def _launch(world, backend, days, total, timeout=600, extra_env=None):
+def _launch(world, backend, days, total, timeout=600, extra_env=None, mode=None):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-           os.path.join(ROOT, 'tests', 'dist_worker.py'), backend, str(days), str(total)]
+           os.path.join(ROOT, 'tests', 'dist_worker.py'), backend, str(days), str(total)] + ([mode] if mode else [])
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1')
     env.update(extra_env or {})
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
@@ -33,6 +33,14 @@ def test_gloo_sharded_run_equals_in_process_sharded_run(world):
     r = _launch(world, 'gloo', 100, 40000)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'DIST_OK world=%d' % world in r.stdout
+
+
+def test_gloo_ensemble_is_partitioned_over_the_ranks():
+    """BASELINE config 5 (replicas only): 7 seeds over 2 ranks, gathered on rank 0, every member identical
+    to its single run"""
+    r = _launch(2, 'gloo', 40, 8000, mode='ensemble')
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'ENSEMBLE_OK world=2 members=7' in r.stdout
 
 
 def test_population_split_is_a_partition():
