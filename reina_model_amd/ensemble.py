@@ -23,9 +23,13 @@ import numpy as np
 from . import simulation
 
 
-def run_group_plan(contexts, plan, record_history=True):
+def run_group_plan(contexts, plan, record_history=True, member_plans=None):
     """Execute `plan` (Context.make_plan) for all `contexts` as one engine group.  Returns
-    history[len(contexts), days, COUNTER_WORDS] (host) or None."""
+    history[len(contexts), days, COUNTER_WORDS] (host) or None.
+
+    `member_plans` (one plan per context, see run_sweep): an intervention sweep -- the members' scenarios
+    differ in the VALUES of their mobility limits / mask shares only, so they share the day descriptors
+    of `plan` while every member gets its own contact tables at each table change."""
     from . import engine as _eng
     group = _eng.EngineGroup([c.engine for c in contexts])
     a = group.alloc
@@ -34,14 +38,18 @@ def run_group_plan(contexts, plan, record_history=True):
     hist = a.zeros(K * days * _eng.COUNTER_WORDS, np.int32) if record_history else None
     row = 4 * _eng.COUNTER_WORDS
     done = 0
-    for tables, arr, n in plan['segments']:
-        if tables is not None:
+    for si, (tables, arr, n) in enumerate(plan['segments']):
+        if member_plans is not None:
+            for c, mp in zip(contexts, member_plans):
+                if mp['segments'][si][0] is not None:
+                    c.engine.upload_contact_tables(*mp['segments'][si][0])
+        elif tables is not None:
             group.upload_contact_tables(*tables)
         ptrs = [a.ptr(hist) + row * (m * days + done) for m in range(K)] if record_history else None
         group.run_day_array(arr, n, ptrs)
         done += n
-    for c in contexts:
-        c.mobility_history = plan['mobility_history']
+    for m, c in enumerate(contexts):
+        c.mobility_history = (member_plans[m] if member_plans is not None else plan)['mobility_history']
         c.day = plan['start_day'] + days
     out = None
     if record_history:
@@ -50,6 +58,36 @@ def run_group_plan(contexts, plan, record_history=True):
         c._raise_on_problem(c.engine.read_counters())
     group.close()
     return out
+
+
+def _same_day_descriptors(p, q):
+    import ctypes
+    if len(p['segments']) != len(q['segments']):
+        return False
+    for (_, a, n), (_, b, m) in zip(p['segments'], q['segments']):
+        if n != m or ctypes.string_at(a, ctypes.sizeof(a)) != ctypes.string_at(b, ctypes.sizeof(b)):
+            return False
+    return True
+
+
+def run_sweep(variables_list, seeds, days, age_counts=None, device='cuda:0', engine_factory=None):
+    """BASELINE config 5's "intervention sweep": member m runs scenario variables_list[m] with seed
+    seeds[m], all as ONE engine group.  The scenarios must agree in everything that goes into the day
+    descriptors (dates, testing modes, imports, vaccination, capacities) and in the dates of their
+    limit-mobility / wear-masks interventions; they may differ in those interventions' values (each member
+    gets its own contact tables).  Returns (history[len(seeds), days, COUNTER_WORDS], contexts)."""
+    assert len(variables_list) == len(seeds)
+    plans, ctxs = [], []
+    for v, sd in zip(variables_list, seeds):
+        planner = simulation.make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory)
+        plans.append(planner.make_plan(days))
+        del planner
+        ctxs.append(simulation.make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory))
+    for k, p in enumerate(plans[1:], 1):
+        if not _same_day_descriptors(plans[0], p):
+            raise ValueError('scenario %d differs from scenario 0 in more than the values of its mobility / mask '
+                             'interventions: it cannot share a group' % k)
+    return run_group_plan(ctxs, plans[0], member_plans=plans), ctxs
 
 
 def run_ensemble_distributed(variables, seeds, days, group=None, concurrent=64, **kw):

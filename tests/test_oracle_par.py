@@ -233,3 +233,43 @@ def test_vectorised_frames_equal_the_per_day_path():
         a, b = df1[col].values, df2[col].values
         assert np.array_equal(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)), col
     assert (adf1.values == adf2.values).all() and list(adf1.columns) == list(adf2.columns)
+
+
+def test_intervention_sweep_as_one_group():
+    """BASELINE config 5's intervention sweep: members with different mobility-limit / mask VALUES (same
+    dates) share one engine group with per-member contact tables; every member equals its own run.
+    A scenario that differs in a date or in a testing mode is refused."""
+    import copy
+    import numpy as np
+    import par_backend
+    import pytest
+    from reina_model_amd import datasets, ensemble, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    ages = datasets.scaled_population(7000)
+
+    def scenario(scale, masks):
+        v = copy.deepcopy(VARIABLE_DEFAULTS)
+        v.update(hospital_beds=8, icu_units=2)
+        ivs = []
+        for iv in v['interventions']:
+            iv = list(iv)
+            if iv[0] == 'limit-mobility':
+                iv[2] = int(iv[2] * scale)
+            if iv[0] == 'wear-masks':
+                iv[2] = masks
+            ivs.append(iv)
+        v['interventions'] = ivs
+        return v
+
+    vs = [scenario(1.0, 80), scenario(0.5, 30), scenario(0.0, 100)]
+    seeds = [5, 5, 9]
+    hist, ctxs = ensemble.run_sweep(vs, seeds, 150, age_counts=ages, engine_factory=par_backend.par_engine_factory)
+    for m in range(3):
+        one = simulation.make_context(vs[m], age_counts=ages, seed=seeds[m], engine_factory=par_backend.par_engine_factory)
+        assert np.array_equal(hist[m], one.run(150)), m
+        assert ctxs[m].mobility_history == one.mobility_history
+    assert not np.array_equal(hist[0], hist[1])          # the sweep did change the epidemic
+    bad = scenario(1.0, 80)
+    bad['interventions'] = [iv for iv in bad['interventions'] if iv[0] != 'test-with-contact-tracing']
+    with pytest.raises(ValueError):
+        ensemble.run_sweep([vs[0], bad], [1, 2], 150, age_counts=ages, engine_factory=par_backend.par_engine_factory)

@@ -427,3 +427,33 @@ def test_extreme_random_scenarios(case):
     if ipc is not None:
         ipc = {k: min(val, total // 12) for k, val in ipc.items()}
     _run_and_compare(v, ages, int(rng.integers(0, 2 ** 31)), min(days, 90), interventions=ivs, chunk=30, ipc=ipc)
+
+
+def test_intervention_sweep_group():
+    """config 5's intervention sweep on the GPU: three scenarios differing in their mobility / mask values
+    as one engine group with per-member contact tables; each member bit-exact vs its own oracle-B run"""
+    import par_backend
+    from reina_model_amd import ensemble
+    ages = datasets.scaled_population(40000)
+
+    def scenario(scale, masks):
+        v = copy.deepcopy(VARIABLE_DEFAULTS)
+        v.update(hospital_beds=20, icu_units=3)
+        ivs = []
+        for iv in v['interventions']:
+            iv = list(iv)
+            if iv[0] == 'limit-mobility':
+                iv[2] = int(iv[2] * scale)
+            if iv[0] == 'wear-masks':
+                iv[2] = masks
+            ivs.append(iv)
+        v['interventions'] = ivs
+        return v
+
+    vs = [scenario(1.0, 80), scenario(0.5, 30), scenario(0.25, 100)]
+    seeds = [5, 5, 9]
+    hist, ctxs = ensemble.run_sweep(vs, seeds, 200, age_counts=ages)
+    for m in range(3):
+        cpu = simulation.make_context(vs[m], age_counts=ages, seed=seeds[m], engine_factory=par_backend.par_engine_factory)
+        assert np.array_equal(hist[m], cpu.run(200)), m
+        _assert_state_equal(ctxs[m], cpu)
