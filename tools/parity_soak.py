@@ -7,6 +7,36 @@ import test_parity_gpu as T
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 bad = 0
 t0 = time.time()
+if len(sys.argv) > 2 and sys.argv[2] == 'sharded':
+    # the same randomised scenarios on a population split over 2-4 in-process shards, HIP vs oracle B
+    import par_backend
+    from reina_model_amd import sharding, simulation
+    for case in range(n):
+        rng = np.random.default_rng(300000 + case)
+        v, ages, days, ivs, ipc = T._random_scenario(rng)
+        G = int(rng.integers(2, 5))
+        seed = int(rng.integers(0, 2 ** 31))
+        gm, cm = [], []
+        try:
+            gpu = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=ivs, ipc=ipc,
+                                           comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
+            cpu = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=ivs, ipc=ipc,
+                                           comm=sharding.InProcessComm(r, G, cm),
+                                           engine_factory=par_backend.par_engine_factory) for r in range(G)]
+            for d in range(min(days, 100)):
+                sharding.step_shards_together(gpu)
+                sharding.step_shards_together(cpu)
+                if d % 10 == 9:
+                    for a, b in zip(gpu, cpu):
+                        assert np.array_equal(a.engine.read_counters(), b.engine.read_counters()), 'day %d' % d
+            for a, b in zip(gpu, cpu):
+                assert np.array_equal(a.engine.read_counters(), b.engine.read_counters()), 'final'
+                T._assert_state_equal(a, b)
+        except AssertionError as e:
+            bad += 1
+            print('MISMATCH sharded case %d (G=%d): %s' % (case, G, str(e)[:300]), flush=True)
+    print('sharded soak: %d scenarios, %d mismatches, %.0f s' % (n, bad, time.time() - t0))
+    sys.exit(0)
 for case in range(n):
     for kind, seed0 in (('random', 100000), ('extreme', 200000)):
         rng = np.random.default_rng(seed0 + case)
