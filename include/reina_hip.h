@@ -86,6 +86,7 @@ enum {
     REINA_L_DAY_OPEN,                                   /* day + 1 once that day's snapshot / zeroing is done */
     REINA_L_TRACE_DONE,                                 /* level-0 tracing workgroups finished today (folded level 1) */
     REINA_L_CAND_OVF,                                   /* candidate records that did not fit their slice's region today */
+    REINA_L_HOSP_PEAK,                                  /* busiest multi-range day so far: its bed / ICU event count (0: every day fit one pass) */
     REINA_L_VACC_CURSOR = 16,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_NR = 32
 };
@@ -94,7 +95,8 @@ typedef struct {
     uint32_t n_agents;        /* agents of this engine instance, sorted by age */
     uint32_t nr_ages;         /* A */
     uint32_t nr_variants;     /* V */
-    uint32_t reserved0;
+    uint32_t max_hosp_events;  /* capacity of buffers.hosp_events (0 = REINA_MAX_HOSP_EVENTS, the number one pass of the
+                                  event walk holds in LDS; more events a day are walked in priority ranges) */
     uint64_t seed;            /* Philox key (random_seed of Context, main.pyx:1759); same on all shards,
                                  the engine mixes the rank in */            /* Philox key (random_seed of Context, main.pyx:1759) */
     uint32_t max_work_items;  /* capacity of work_items (records) */

@@ -423,7 +423,7 @@ static void run_vaccinations(Par *e, const reina_day_t *dp) {
 
 /* ---------------------------------------------------------------- scan */
 static void emit_event(Par *e, uint32_t i, uint32_t day, int type) {
-    if (CTL(e, REINA_L_HOSP) >= REINA_MAX_HOSP_EVENTS) {
+    if ((uint32_t)CTL(e, REINA_L_HOSP) >= (e->cfg.max_hosp_events ? e->cfg.max_hosp_events : REINA_MAX_HOSP_EVENTS)) {
         set_problem(e, REINA_PROBLEM_HOSPITAL_OVERFLOW);
         return;
     }

@@ -42,6 +42,7 @@ S_INFECTED_BY_VARIANT = 24
 S_NR = 32
 COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 32
+L_HOSP_PEAK = 12   # control word: event count of the busiest day that needed several priority ranges
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
                  'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
@@ -51,7 +52,7 @@ ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial
 
 class Config(ctypes.Structure):
     _fields_ = [('n_agents', ctypes.c_uint32), ('nr_ages', ctypes.c_uint32),
-                ('nr_variants', ctypes.c_uint32), ('reserved0', ctypes.c_uint32),
+                ('nr_variants', ctypes.c_uint32), ('max_hosp_events', ctypes.c_uint32),
                 ('seed', ctypes.c_uint64),
                 ('max_work_items', ctypes.c_uint32), ('max_candidates', ctypes.c_uint32),
                 ('max_queue', ctypes.c_uint32), ('n_shards', ctypes.c_uint32),
@@ -226,7 +227,8 @@ class Engine:
             work_items=a.zeros(4 * config.max_work_items, np.uint32),
             candidates=a.zeros(4 * config.max_candidates, np.uint32),
             queue0=a.zeros(config.max_queue, np.uint32), queue1=a.zeros(config.max_queue, np.uint32),
-            level1=a.zeros(config.max_queue, np.uint32), hosp_events=a.zeros(MAX_HOSP_EVENTS, np.uint64),
+            level1=a.zeros(config.max_queue, np.uint32),
+            hosp_events=a.zeros(max(MAX_HOSP_EVENTS, config.max_hosp_events), np.uint64),
             pressure=a.zeros(PRESSURE_WORDS, np.int32),
             mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 32, np.uint64),
             mirror_meta=a.zeros(2 * MAX_RANGES * MAX_VARIANTS, np.uint32),

@@ -457,3 +457,19 @@ def test_intervention_sweep_group():
         cpu = simulation.make_context(vs[m], age_counts=ages, seed=seeds[m], engine_factory=par_backend.par_engine_factory)
         assert np.array_equal(hist[m], cpu.run(200)), m
         _assert_state_equal(ctxs[m], cpu)
+
+
+def test_more_bed_events_in_a_day_than_one_pass_holds():
+    """20 M agents, unmitigated wave, scarce beds: at the peak far more than 16 384 bed / ICU events a day,
+    walked in priority ranges with the free-bed / free-unit counts carried from range to range -- per-day
+    counters and final state bit-exact vs oracle B's single sorted walk"""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=20000, icu_units=1500)
+    ivs = [['import-infections', '2020-02-19', 40000], ['import-infections', '2020-02-22', 30000, 'b1.1.7'],
+           ['test-all-with-symptoms', '2020-02-20']]
+    ages = datasets.scaled_population(20_000_000)
+    gpu, cpu = _run_and_compare(v, ages, 8, 70, interventions=ivs, chunk=35)
+    c = gpu.per_age_counters()
+    assert c['all_infected'].sum() > 10_000_000 and c['dead'].sum() > 50_000
+    peak = int(gpu.engine.alloc.to_host(gpu.engine.tensors['control'])[eng.L_HOSP_PEAK])
+    assert peak > 2 * 16384, peak
