@@ -91,12 +91,15 @@ enum {
     REINA_L_NR = 32
 };
 
+/* words of buffers.hosp_events for a day capacity of `cap` events: sort scratch, range bases, two key lists */
+#define REINA_HOSP_EVENT_WORDS(cap) (REINA_MAX_HOSP_EVENTS + 1024 + 2 * ((cap) > REINA_MAX_HOSP_EVENTS ? (cap) : REINA_MAX_HOSP_EVENTS))
+
 typedef struct {
     uint32_t n_agents;        /* agents of this engine instance, sorted by age */
     uint32_t nr_ages;         /* A */
     uint32_t nr_variants;     /* V */
-    uint32_t max_hosp_events;  /* capacity of buffers.hosp_events (0 = REINA_MAX_HOSP_EVENTS, the number one pass of the
-                                  event walk holds in LDS; more events a day are walked in priority ranges) */
+    uint32_t max_hosp_events; /* bed / ICU events one day may hold (0 or less than REINA_MAX_HOSP_EVENTS = that number,
+                                 which one walk holds in LDS; busier days are walked in priority ranges) */
     uint64_t seed;            /* Philox key (random_seed of Context, main.pyx:1759); same on all shards,
                                  the engine mixes the rank in */            /* Philox key (random_seed of Context, main.pyx:1759) */
     uint32_t max_work_items;  /* capacity of work_items (records) */
@@ -179,7 +182,7 @@ typedef struct {
     uint32_t *queue0;         /* [max_queue] testing queue, even days */
     uint32_t *queue1;         /* [max_queue] testing queue, odd days */
     uint32_t *level1;         /* [max_queue] contact-tracing level-1 work list */
-    uint64_t *hosp_events;    /* [REINA_MAX_HOSP_EVENTS] */
+    uint64_t *hosp_events;    /* [REINA_HOSP_EVENT_WORDS(max_hosp_events)]: scratch of the event walk */
     int32_t *pressure;        /* [REINA_PRESSURE_WORDS] cross-shard infection pressure of the day:
                                  [dest shard][contact range][variant] = transmissible contacts aimed at
                                  agents of another shard. Filled by reina_step_day_begin, summed over

@@ -161,6 +161,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         e->h_params.cand_ovf_base = cfg->max_candidates - ovf;
     }
     e->h_params.max_queue = cfg->max_queue;
+    e->h_params.max_hosp_events = cfg->max_hosp_events > REINA_MAX_HOSP_EVENTS ? cfg->max_hosp_events : REINA_MAX_HOSP_EVENTS;
     HIP_CHECK(hipMalloc(&e->d_params, sizeof(DevParams)));
     HIP_CHECK(hipMalloc(&e->d_tables, sizeof(Tables)));
     HIP_CHECK(hipMalloc(&e->d_ref, sizeof(MemberRef)));

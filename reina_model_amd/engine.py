@@ -228,7 +228,8 @@ class Engine:
             candidates=a.zeros(4 * config.max_candidates, np.uint32),
             queue0=a.zeros(config.max_queue, np.uint32), queue1=a.zeros(config.max_queue, np.uint32),
             level1=a.zeros(config.max_queue, np.uint32),
-            hosp_events=a.zeros(max(MAX_HOSP_EVENTS, config.max_hosp_events), np.uint64),
+            # [sort scratch][range bases][the day's keys in list order][the same grouped by priority range]
+            hosp_events=a.zeros(MAX_HOSP_EVENTS + 1024 + 2 * max(MAX_HOSP_EVENTS, config.max_hosp_events), np.uint64),
             pressure=a.zeros(PRESSURE_WORDS, np.int32),
             mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 32, np.uint64),
             mirror_meta=a.zeros(2 * MAX_RANGES * MAX_VARIANTS, np.uint32),
