@@ -94,6 +94,15 @@ class TorchComm:
                 import sys
                 print('reina: direct RCCL communicator unavailable (%s); using torch.distributed' % e, file=sys.stderr)
                 self.direct = None
+            if self.world > 1:
+                # every rank must take the same route: one rank on torch.distributed while the others sit in
+                # the direct communicator's all-reduce would hang the day loop
+                ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32,
+                                  device=torch.device('cuda', torch.cuda.current_device()))
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if int(ok.item()) == 0 and self.direct is not None:
+                    self.direct.close()
+                    self.direct = None
 
     def _as_tensor(self, buf):
         if isinstance(buf, np.ndarray):
