@@ -262,6 +262,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--agents', type=int, default=0, help='synthetic population per GPU (0 = HUS)')
     ap.add_argument('--large-agents', type=int, default=50_000_000)
+    ap.add_argument('--xlarge-agents', type=int, default=200_000_000,
+                    help='SURVEY 8d: a population well past the 256 MB Infinity Cache (0 = skip)')
     ap.add_argument('--cpu-days', type=int, default=120)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-large', action='store_true')
@@ -374,6 +376,22 @@ def main():
                 'roofline': roofline_obj(nl, a.steps, profl, statsl, a.time_every, dtl * 1000 / a.steps),
                 'final_all_infected': statsl['final_all_infected'],
             }
+            try:   # PMC traffic of the same workload (profiles/traffic.json, collected in separate --pmc passes)
+                out['large']['roofline']['traffic'] = json.load(open(traffic_file)).get(str(a.large_agents))
+            except Exception:
+                pass
+            if a.xlarge_agents:
+                # SURVEY 8d's second point: a hot array (0.8 GB) that no cache level holds
+                vx, agesx = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.xlarge_agents)
+                dtx, profx, statsx, nx = run_gpu(vx, agesx, a.seed, a.steps, a.warmup, device, preheat=min(a.preheat_days, 30),
+                                                 stride=a.time_every, preheat_runs=1)
+                out['xlarge'] = {
+                    'workload': 'synthetic %d agents (SURVEY 8d: HBM-resident regime), default scenario scaled, %d days' % (nx, a.steps),
+                    'value': round(nx * a.steps / dtx, 1), 'unit': 'agent-days/s',
+                    'ms_per_step': round(dtx * 1000 / a.steps, 6),
+                    'roofline': roofline_obj(nx, a.steps, profx, statsx, a.time_every, dtx * 1000 / a.steps),
+                    'final_all_infected': statsx['final_all_infected'],
+                }
         if large_sharded is not None:
             out['large'] = large_sharded
         if not a.no_ensemble and world == 1 and not a.agents:
@@ -382,6 +400,11 @@ def main():
             hus = datasets.get_population_for_area()
             out['cpu_baseline'] = cpu_baseline(copy.deepcopy(VARIABLE_DEFAULTS), hus, a.seed, a.cpu_days)
             out['cpu_baseline']['cores_available'] = os.cpu_count()
+            try:
+                with open('/proc/cpuinfo') as f:
+                    out['cpu_baseline']['cpu_model'] = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
+            except Exception:
+                pass
             if cpu_all is not None:
                 res = cpu_all.run()
                 if res is not None:
