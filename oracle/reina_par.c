@@ -185,9 +185,9 @@ static int severity_of(const Par *e, int age, float val, float vmod, int *pod_ou
 
 static uint32_t clamp_days(Par *e, int d) {
     if (d < 0) d = 0;
-    if (d > 255) {
+    if (d > RH_MAX_DAYS) {
         set_problem(e, REINA_PROBLEM_DAYS_OVERFLOW);
-        d = 255;
+        d = RH_MAX_DAYS;
     }
     return (uint32_t)d;
 }
@@ -207,7 +207,9 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
     uint32_t dl = clamp_days(e, rp_round_to_int(g));
     uint32_t nw = RS_INCUBATION | ((uint32_t)sev << 3) | (variant << 8) | (pod ? RH_POD_OUTSIDE : 0) |
                   (fresh ? RH_FRESH : 0) | (w & RH_VACCINATED) |
-                  (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0) | (dl << 16);
+                  (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0) |
+                  /* (a FRESH agent of the initial condition sits out the scan of day 0 first) */
+                  RH_DAYS_FIELD(dl, (fresh && day == RP_INIT_DAY) ? day + 1u : day);
     e->buf.hot[t] = nw;
     e->buf.sus_bits[t >> 5] &= ~(1u << (t & 31));
     if (src >= 0) {
@@ -444,8 +446,8 @@ static uint32_t onset_word(Par *e, uint32_t i, uint32_t w, uint32_t day) {
     float f = d;
     if (sev >= RV_SEVERE) f *= e->dis.ratio_of_duration_before_hospitalisation[v];
     w = RH_SET_STATE(w, RS_ILLNESS);
-    w = RH_SET_DAYS_LEFT(w, clamp_days(e, rp_round_to_int(f)));
-    w = RH_SET_DOI(w, 0);
+    w = RH_SET_DAYS_LEFT(w, clamp_days(e, rp_round_to_int(f)), day);
+    w = RH_SET_DOI0(w, day);
     return w;
 }
 
@@ -492,13 +494,13 @@ static void run_scan(Par *e, const reina_day_t *dp) {
         }
         int age = age_of(e, i);
         int v = RH_VARIANT(w), sev = RH_SEV(w);
-        uint32_t dl = RH_DAYS_LEFT(w);
+        uint32_t dl = RH_DAYS_LEFT(w, dp->day);   /* absolute days in the word: waiting leaves it unchanged */
         if (st == RS_INCUBATION || st == RS_ILLNESS) {
             /* person_expose_others -> get_exposed_people -> get_contacts (main.pyx:247-281,936-955,
              * 1308-1320,1539-1573): only the COUNT is drawn here, contacts are realised later */
             int nr = 0;
             if (!(w & RH_DETECTED)) {
-                int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w);
+                int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w, dp->day);
                 float inf = (dayrel >= -10 && dayrel <= 10) ? d->infectiousness_over_time[v][dayrel + 10] : 0.0f;
                 if (inf != 0.0f) {
                     float factor = 1.0f;
@@ -531,15 +533,9 @@ static void run_scan(Par *e, const reina_day_t *dp) {
             SC(e, REINA_S_EXPOSED_PER_DAY) += nr;
             if (st == RS_INCUBATION) {
                 if (dl > 0) dl--;
-                if (dl == 0)
-                    w = become_ill(e, i, w, dp);
-                else
-                    w = RH_SET_DAYS_LEFT(w, dl);
+                if (dl == 0) w = become_ill(e, i, w, dp);
             } else {
-                uint32_t doi = RH_DOI(w);
-                if (doi < 255) doi++;
                 if (dl > 0) dl--;
-                w = RH_SET_DOI(RH_SET_DAYS_LEFT(w, dl), doi);
                 if (dl == 0) {
                     if (sev == RV_FATAL && (w & RH_POD_OUTSIDE))
                         w = do_die(e, w, age);
@@ -551,11 +547,9 @@ static void run_scan(Par *e, const reina_day_t *dp) {
             }
         } else if (st == RS_HOSPITALIZED) {
             if (dl > 0) dl--;
-            w = RH_SET_DAYS_LEFT(w, dl);
             if (dl == 0) emit_event(e, i, dp->day, sev >= RV_CRITICAL ? EV_TO_ICU : EV_RELEASE_WARD);
         } else { /* IN_ICU */
             if (dl > 0) dl--;
-            w = RH_SET_DAYS_LEFT(w, dl);
             if (dl == 0) emit_event(e, i, dp->day, EV_RELEASE_ICU);
         }
         e->buf.hot[i] = w;
@@ -623,7 +617,7 @@ static void run_hospital_events(Par *e, const reina_day_t *dp) {
                     f = od * (1.0f - d->ratio_of_duration_before_hospitalisation[v]);
                 else
                     f = od * d->ratio_of_duration_in_ward[v];
-                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)));
+                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)), dp->day);
                 CNT(e, REINA_C_HOSPITALIZED, age) += 1;
                 CNT(e, REINA_C_IN_WARD, age) += 1;
             }
@@ -638,7 +632,7 @@ static void run_hospital_events(Par *e, const reina_day_t *dp) {
             } else {
                 float f = 1.0f - d->ratio_of_duration_in_ward[v] - d->ratio_of_duration_before_hospitalisation[v];
                 f *= od;
-                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)));
+                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)), dp->day);
                 CNT(e, REINA_C_IN_WARD, age) -= 1;
                 CNT(e, REINA_C_IN_ICU, age) += 1;
                 CNT(e, REINA_C_CUM_ICU, age) += 1;
@@ -741,7 +735,7 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
                     b--;
                     float f = sev == RV_SEVERE ? od * (1.0f - d->ratio_of_duration_before_hospitalisation[v])
                                                : od * d->ratio_of_duration_in_ward[v];
-                    w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)));
+                    w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)), RP_INIT_DAY);
                     CNT(e, REINA_C_HOSPITALIZED, age) += 1;
                     CNT(e, REINA_C_IN_WARD, age) += 1;
                 } else {
@@ -752,7 +746,7 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
                     } else {
                         float f = 1.0f - d->ratio_of_duration_in_ward[v] - d->ratio_of_duration_before_hospitalisation[v];
                         f *= od;
-                        w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)));
+                        w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)), RP_INIT_DAY);
                         CNT(e, REINA_C_HOSPITALIZED, age) += 1;
                         CNT(e, REINA_C_IN_ICU, age) += 1;
                         CNT(e, REINA_C_CUM_ICU, age) += 1;

@@ -227,11 +227,22 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 #define RH_FRESH 0x1000u
 #define RH_VACCINATED 0x2000u
 #define RH_HASLIST 0x4000u
-#define RH_DAYS_LEFT(w) (((w) >> 16) & 0xFFu)
-#define RH_DOI(w) ((w) >> 24)
 #define RH_SET_STATE(w, s) (((w) & ~7u) | (uint32_t)(s))
-#define RH_SET_DAYS_LEFT(w, d) (((w) & ~0x00FF0000u) | ((uint32_t)(d) << 16))
-#define RH_SET_DOI(w, d) (((w) & 0x00FFFFFFu) | ((uint32_t)(d) << 24))
+// days_left / day_of_illness are kept as ABSOLUTE days (mod 256), so the word of an agent that is only
+// waiting does not change from one day to the next (no daily write-back): bits 16-23 = the day whose
+// scan finds days_left == 0 before its own decrement, bits 24-31 = the day whose scan finds
+// day_of_illness == 0.  A countdown never sits at 0 for a second scan (every state leaves on the day
+// it gets there: person_advance main.pyx:395-438), so the difference mod 256 is the countdown itself,
+// 0..255 as in the counting form.
+#define RH_MAX_DAYS 255
+// the countdown as the scan of `day` finds it (before that scan's decrement)
+#define RH_DAYS_LEFT(w, day) ((uint32_t)((((w) >> 16) - (day)) & 0xFFu))
+#define RH_DOI(w, day) ((uint32_t)(((day) - ((w) >> 24)) & 0xFFu))
+// written by code that runs on `day` (after that day's scan, before it for a FRESH import, RP_INIT_DAY
+// = -1 while the initial condition is applied): the NEXT day's scan finds days_left == d / day_of_illness == 0
+#define RH_DAYS_FIELD(d, day) ((((uint32_t)(day) + 1u + (uint32_t)(d)) & 0xFFu) << 16)
+#define RH_SET_DAYS_LEFT(w, d, day) (((w) & ~0x00FF0000u) | RH_DAYS_FIELD(d, day))
+#define RH_SET_DOI0(w, day) (((w) & 0x00FFFFFFu) | ((((uint32_t)(day) + 1u) & 0xFFu) << 24))
 
 enum { RS_SUSCEPTIBLE = 0, RS_INCUBATION, RS_ILLNESS, RS_HOSPITALIZED, RS_IN_ICU, RS_RECOVERED, RS_DEAD };
 enum { RV_ASYMPTOMATIC = 0, RV_MILD, RV_SEVERE, RV_CRITICAL, RV_FATAL };
