@@ -392,6 +392,10 @@ def main():
                     'roofline': roofline_obj(nx, a.steps, profx, statsx, a.time_every, dtx * 1000 / a.steps),
                     'final_all_infected': statsx['final_all_infected'],
                 }
+                try:
+                    out['xlarge']['roofline']['traffic'] = json.load(open(traffic_file)).get(str(a.xlarge_agents))
+                except Exception:
+                    pass
         if large_sharded is not None:
             out['large'] = large_sharded
         if not a.no_ensemble and world == 1 and not a.agents:

@@ -20,7 +20,7 @@ P = os.path.join(ROOT, 'profiles')
 os.makedirs(P, exist_ok=True)
 traffic = {}
 pmc_rows = [['config', 'counter', 'launches', 'mean_KB', 'min_KB', 'max_KB']]
-for cfg, key in (('hus', 'hus'), ('50m', '50000000')):
+for cfg, key in (('hus', 'hus'), ('50m', '50000000'), ('200m', '200000000')):
     st = glob.glob(os.path.join(G, '%s_trace_%s' % (tag, cfg), '*', '*kernel_stats.csv'))
     if st:
         shutil.copy(st[0], os.path.join(P, '%s_kernel_stats_%s.csv' % (tag, cfg)))
