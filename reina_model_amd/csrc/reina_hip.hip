@@ -296,7 +296,18 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
 // scanning waves of one engine instance: one 512-agent tile per wave (small populations) up to 8192
 // waves; members of a group share the chip, so each gets its part of ~2048 workgroups and its
 // waves walk several tiles (every later kernel takes the wave count as a parameter)
-static uint32_t scan_blocks_for(uint32_t n_agents, uint32_t K) {
+// workgroups of the contact sampling for one member (the event workgroup comes on top)
+static uint32_t con_blocks_for(uint32_t scan_waves, uint32_t n_cus, uint32_t K) {
+    uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
+    if (con_blocks > n_cus - 1) con_blocks = n_cus - 1;  // with the event workgroup: one resident wave of workgroups (256 CUs on MI355X)
+    if (K > 1) {  // a group: 256 workgroups for all members together, each staging its tables once for more slices
+        const uint32_t per = n_cus / K > 1u ? n_cus / K - 1u : 1u;
+        if (con_blocks > per) con_blocks = per;
+    }
+    return con_blocks;
+}
+
+static uint32_t scan_blocks_for(uint32_t n_agents, uint32_t K, uint32_t n_cus) {
     const uint32_t scan_tiles = ((n_agents >> 2) + 127u) / 128u;
     uint32_t b = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;
     if (b < 1) b = 1;
@@ -306,6 +317,11 @@ static uint32_t scan_blocks_for(uint32_t n_agents, uint32_t K) {
         if (per < 16) per = 16;
         if (b > per) b = per;
     }
+    // The scanning waves' slices are dealt out to the contact waves round robin: with 8192 slices for 4080
+    // contact waves, 32 waves would work a third slice while 254 CUs idle (+50 % on the kernel).  With two or
+    // more slices per contact wave the slice count is therefore rounded down to a multiple of the contact waves.
+    const uint32_t unit = con_blocks_for(b * SCAN_WAVES, n_cus, K) * CON_WAVES / SCAN_WAVES;   // blocks per "one slice each"
+    if (unit > 0 && b >= 2 * unit) b -= b % unit;
     return b;
 }
 
@@ -339,7 +355,7 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
     // scan geometry: tiles of 512 agents, as many waves as tiles (small populations) up to 8192
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-    const uint32_t scan_blocks = scan_blocks_for(N, K);
+    const uint32_t scan_blocks = scan_blocks_for(N, K, e->n_cus);
     const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
     if (e->profile && K == 1 && dp.day % e->profile_stride == 0) {
         // start/stop timestamps ride on the kernel's own dispatch packet: no extra stream commands
@@ -351,12 +367,7 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         hipLaunchKernelGGL(k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, refs, dp);
     }
     {   // bed / ICU events (workgroup 0, latency-bound) beside the contact sampling (workgroups 1..)
-        uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
-        if (con_blocks > e->n_cus - 1) con_blocks = e->n_cus - 1;  // with the event workgroup: one resident wave of workgroups (256 CUs on MI355X)
-        if (K > 1) {  // a group: 256 workgroups for all members together, each staging its tables once for more slices
-            const uint32_t per = e->n_cus / K > 1u ? e->n_cus / K - 1u : 1u;
-            if (con_blocks > per) con_blocks = per;
-        }
+        const uint32_t con_blocks = con_blocks_for(scan_waves, e->n_cus, K);
         size_t lds = con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards);
         if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
         // slices per contact wave and step: 1 while every slice has a wave of its own, up to 8 otherwise
@@ -376,7 +387,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-        const uint32_t scan_blocks = scan_blocks_for(N, K);
+        const uint32_t scan_blocks = scan_blocks_for(N, K, e->n_cus);
         int ig = grid_for(N / 64 + 1, 256, 512) * 2;  // even: candidates / deferred lists
         if (K > 1 && ig > (int)(4096 / K)) ig = (int)(4096 / K) >= 2 ? ((int)(4096 / K) & ~1) : 2;
         hipLaunchKernelGGL(k_install, dim3(ig, K), dim3(256), 0, s, refs, dp, scan_blocks * SCAN_WAVES, scan_tiles);

@@ -215,8 +215,8 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 //  bit   12   fresh: infected before today's scan (day_of_infection == today, main.pyx:402)
 //  bit   13   vaccinated (day_of_vaccination >= 0)
 //  bit   14   has infectee list (infected while contact tracing was on, main.pyx:227-233)
-//  bits 16-23 days_left (saturating 255)
-//  bits 24-31 day_of_illness (saturating 255)
+//  bits 16-23 days_left, as the absolute day (mod 256) whose scan finds it at 0 (see RH_DAYS_LEFT below)
+//  bits 24-31 day_of_illness, as the absolute day (mod 256) whose scan finds it at 0
 #define RH_STATE(w) ((w) & 7u)
 #define RH_SEV(w) (((w) >> 3) & 7u)
 #define RH_DETECTED 0x40u
