@@ -316,6 +316,18 @@ int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_
  * 4 hospitalization_period, 5 icu_period, 6 onset_to_removed_period; severity < 0 = None */
 int reina_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,
                  float nr_contacts_of_age, int n, int32_t *out);
+/* replaces ContactMatrix.generate_contact_probabilities (main.pyx:1184-1235; pandas in the reference, run
+ * by init_day :1285-1288 whenever a mobility limitation changes) for a matrix whose ages all have E
+ * entries, and packs the thresholds of reina_contact_tables_t; host-only, needs no engine and no GPU.
+ * base / row_page / row_place: the long-form contact rows (contacts per day, participant age, place);
+ * mobility: n_mobility x (place or -1, min_age, max_age, factor) as doubles, applied in order;
+ * rows_mat / sorted_mat [A*E]: each age's rows in summation order / in table order.
+ * Out: totals [A] (nr_contacts_by_age), cum [A*E] (cumulative probabilities), and, if not NULL,
+ * nrc [A] (float) and thr [A*thr_stride] (uint32 thresholds, entries past E untouched). */
+int reina_build_contact_tables(const double *base, const int32_t *row_page, const int32_t *row_place, uint32_t n_rows,
+                               const double *mobility, uint32_t n_mobility, const int32_t *rows_mat,
+                               const int32_t *sorted_mat, uint32_t n_ages, uint32_t n_entries, double *totals_out,
+                               double *cum_out, float *nrc_out, uint32_t *thr_out, uint32_t thr_stride);
 const char *reina_last_error(void);
 int reina_abi_version(void);
 

@@ -31,6 +31,7 @@
 #include "../../include/reina_hip.h"
 #include "reina_prims.h"
 #include "reina_sample.h"
+#include "reina_contacts.h"
 
 #define CNT_IDX(c, age) ((c) * REINA_MAX_AGES + (age))
 #define SC_IDX(s) (REINA_C_NR * REINA_MAX_AGES + (s))
@@ -87,6 +88,15 @@ static void resolve_profile(reina_engine *e) {
 extern "C" {
 
 int reina_abi_version(void) { return 1; }
+
+int reina_build_contact_tables(const double *base, const int32_t *row_page, const int32_t *row_place, uint32_t n_rows,
+                               const double *mobility, uint32_t n_mobility, const int32_t *rows_mat,
+                               const int32_t *sorted_mat, uint32_t n_ages, uint32_t n_entries, double *totals_out,
+                               double *cum_out, float *nrc_out, uint32_t *thr_out, uint32_t thr_stride) {
+    const int rc = reina_build_contact_tables_impl(base, row_page, row_place, n_rows, mobility, n_mobility, rows_mat, sorted_mat,
+                                                   n_ages, n_entries, totals_out, cum_out, nrc_out, thr_out, thr_stride);
+    return rc == 0 ? REINA_OK : REINA_E_INVALID;
+}
 
 int reina_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,
                  float nr_contacts_of_age, int n, int32_t *out) {

@@ -47,7 +47,7 @@ L_HOSP_PEAK = 12   # control word: event count of the busiest day that needed se
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
                  'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
                  'group_create', 'group_destroy', 'group_upload_contact_tables', 'group_run_days',
-                 'last_error', 'abi_version')
+                 'build_contact_tables', 'last_error', 'abi_version')
 
 
 class Config(ctypes.Structure):
@@ -148,6 +148,8 @@ def bind_abi(lib, prefix):
     f['group_run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, ctypes.POINTER(vp), vp]
     f['sample'].argtypes = [ctypes.POINTER(Disease), ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                             ctypes.c_float, ctypes.c_int, vp]
+    f['build_contact_tables'].argtypes = [vp, vp, vp, ctypes.c_uint32, vp, ctypes.c_uint32, vp, vp, ctypes.c_uint32,
+                                          ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint32]
     f['profile_enable'].argtypes = [vp, ctypes.c_int]
     f['profile_read'].argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                                   ctypes.POINTER(ctypes.c_double)]

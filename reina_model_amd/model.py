@@ -159,6 +159,9 @@ _static_pack_cache = {}
 def _static_pack(tables):
     """(ranges, range id per entry, meta words): depend only on the entry keys, which never change
     for a given ContactMatrix; cached by the identity of its key arrays."""
+    ident = _static_pack_cache.get('ident')   # the very same key arrays as last time (native builder): no hashing
+    if ident is not None and ident[0] is tables.place and ident[1] is tables.cmin and ident[2] is tables.cmax:
+        return ident[3]
     key = (tables.place.tobytes(), tables.cmin.tobytes(), tables.cmax.tobytes())
     hit = _static_pack_cache.get(key)
     if hit is None:
@@ -170,21 +173,34 @@ def _static_pack(tables):
         rid = np.asarray([range_id[r] for r in pairs], dtype=np.uint32)
         m_all = (tables.place.astype(np.uint32) | (tables.cmin.astype(np.uint32) << 8)
                  | (tables.cmax.astype(np.uint32) << 16) | (rid << 24))
-        hit = (ranges, m_all)
+        hit = (ranges, m_all, {})   # {}: the padded meta array per (ages, entries per age), built on first use
         _static_pack_cache.clear()
         _static_pack_cache[key] = hit
+    _static_pack_cache['ident'] = (tables.place, tables.cmin, tables.cmax, hit)
     return hit
 
 
 def pack_contact_tables(tables, nr_ages):
     """ContactTables (contacts.py) -> the fixed-shape arrays of reina_contact_tables_t."""
     E = _eng.MAX_ENTRIES
+    ranges, m_all, padded = _static_pack(tables)
+    packed = getattr(tables, 'packed', None)
+    if packed is not None:   # built by the library's host-side builder, thresholds included
+        nrc, thr = packed
+        c = int(tables.count[0])
+        hit = padded.get((nr_ages, c))
+        if hit is None:
+            count = np.zeros(_eng.MAX_AGES, dtype=np.int32)
+            meta = np.zeros((_eng.MAX_AGES, E), dtype=np.uint32)
+            count[:nr_ages] = c
+            meta[:nr_ages, :c] = m_all.reshape(nr_ages, c)
+            hit = padded[(nr_ages, c)] = (count, meta)
+        return nrc, hit[0], thr, hit[1], ranges
     nrc = np.zeros(_eng.MAX_AGES, dtype=np.float32)
     nrc[:nr_ages] = tables.nr_contacts_by_age.astype(np.float32)
     count = np.zeros(_eng.MAX_AGES, dtype=np.int32)
     thr = np.full((_eng.MAX_AGES, E), 0xFFFFFFFF, dtype=np.uint32)
     meta = np.zeros((_eng.MAX_AGES, E), dtype=np.uint32)
-    ranges, m_all = _static_pack(tables)
     with np.errstate(invalid='ignore'):
         t_all = np.clip(np.floor(np.nan_to_num(tables.cum_p, nan=0.0) * 4294967296.0), 0, 4294967295.0)
     t_all = t_all.astype(np.uint64).astype(np.uint32)
@@ -288,6 +304,9 @@ class Context:
         self.engine.init_state(self._split(self.beds), self._split(self.icu_units))
 
         self.contact_matrix = ContactMatrix(population_params['contacts_per_day'], nr_ages)
+        # table rebuilds on mobility changes go through the library's host-side builder
+        self.contact_matrix.native_build = self.engine.f['build_contact_tables']
+        self.contact_matrix.pack_ages, self.contact_matrix.pack_entries = _eng.MAX_AGES, _eng.MAX_ENTRIES
         self._upload_tables()
 
         # HealthcareSystem host-side settings (main.pyx:461-472)

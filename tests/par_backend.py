@@ -15,7 +15,8 @@ LIB = os.path.join(ORACLE, 'libreina_par.so')
 def build(force=False):
     src = os.path.join(ORACLE, 'reina_par.c')
     deps = [src, os.path.join(ROOT, 'include', 'reina_hip.h'),
-            os.path.join(ROOT, 'reina_model_amd', 'csrc', 'reina_prims.h')]
+            os.path.join(ROOT, 'reina_model_amd', 'csrc', 'reina_prims.h'),
+            os.path.join(ROOT, 'reina_model_amd', 'csrc', 'reina_contacts.h')]
     if (not force and os.path.exists(LIB)
             and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)):
         return LIB

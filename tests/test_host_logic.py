@@ -198,3 +198,58 @@ def test_scenarios_apply_like_the_reference():
     import pytest
     with pytest.raises(Exception):
         scenarios.scenario_variables('nope')
+
+
+def test_native_contact_table_builder_equals_numpy_form():
+    """reina_build_contact_tables / par_build_contact_tables (csrc/reina_contacts.h, what a Context uses
+    when a mobility limitation changes) against the numpy form of generate_contact_probabilities +
+    pack_contact_tables: totals, cumulative probabilities, float32 totals and uint32 thresholds bit for
+    bit, over stacked / overlapping / zeroing factors (an age whose contacts are all switched off has
+    NaN probabilities in the reference: thresholds 0)."""
+    from reina_model_amd.contacts import PLACES, ContactMatrix
+    from reina_model_amd.model import pack_contact_tables
+    build = eng.bind_abi(par_backend.lib(), 'par_')['build_contact_tables']
+    A = 101
+    ROWS = datasets.get_contacts_per_day()
+    rng = np.random.default_rng(5)
+
+    def pair():
+        a, b = ContactMatrix(ROWS, A), ContactMatrix(ROWS, A)
+        b.native_build, b.pack_ages, b.pack_entries = build, eng.MAX_AGES, eng.MAX_ENTRIES
+        return a, b
+
+    def same(a, b):
+        ta, tb = a.generate_contact_probabilities(), b.generate_contact_probabilities()
+        assert getattr(ta, 'packed', None) is None and tb.packed is not None
+        for f in ('nr_contacts_by_age', 'cum_p'):
+            assert np.array_equal(getattr(ta, f).view(np.uint64), getattr(tb, f).view(np.uint64)), f
+        for f in ('offset', 'count', 'place', 'cmin', 'cmax'):
+            assert np.array_equal(getattr(ta, f), getattr(tb, f)), f
+        assert np.array_equal(ta.mask_p, tb.mask_p)
+        pa, pb = pack_contact_tables(ta, A), pack_contact_tables(tb, A)
+        assert np.array_equal(pa[0].view(np.uint32), pb[0].view(np.uint32))       # nr_contacts float32
+        for k in (1, 2, 3):
+            assert np.array_equal(pa[k], pb[k]), k
+        assert pa[4] == pb[4]
+
+    a, b = pair()
+    same(a, b)                                                    # no factors
+    for cm in (a, b):
+        cm.set_mobility_factor(0.5, place=PLACES.index('work'))
+        cm.set_mobility_factor(0.8, place=PLACES.index('school'), min_age=7, max_age=18)
+        cm.set_mobility_factor(0.95)                              # every place, every age
+        cm.set_mask_probability(0.6, place=PLACES.index('transport'), min_age=15)
+    same(a, b)
+    for cm in (a, b):
+        cm.set_mobility_factor(0.0, min_age=80, max_age=100)      # everything off for the oldest: 0 / 0
+        cm.set_mobility_factor(0.3, place=PLACES.index('work'))   # replaces the earlier work factor
+    same(a, b)
+    for _ in range(15):                                           # random stacks
+        a, b = pair()
+        for _k in range(int(rng.integers(1, 12))):
+            lo = int(rng.integers(0, A)); hi = int(rng.integers(lo, A))
+            place = None if rng.random() < 0.25 else int(rng.integers(0, len(PLACES)))
+            f = float(np.float32(rng.choice([0.0, 0.05, 0.33, 0.5, 0.9, 1.0, 1.7])))
+            for cm in (a, b):
+                cm.set_mobility_factor(f, place=place, min_age=lo, max_age=hi)
+        same(a, b)
