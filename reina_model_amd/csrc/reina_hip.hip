@@ -399,7 +399,9 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
         const uint32_t scan_blocks = scan_blocks_for(N, K, e->n_cus);
         int ig = grid_for(N / 64 + 1, 256, 512) * 2;  // even: candidates / deferred lists
-        if (K > 1 && ig > (int)(4096 / K)) ig = (int)(4096 / K) >= 2 ? ((int)(4096 / K) & ~1) : 2;
+        // (groups: 512 workgroups for all members together -- measured on 8 / 32 / 128 HUS-sized members against
+        // 256, 1024, 2048 and 4096: every workgroup pays its prologue and its histogram flush)
+        if (K > 1 && ig > (int)(512 / K)) ig = (int)(512 / K) >= 2 ? ((int)(512 / K) & ~1) : 2;
         hipLaunchKernelGGL(k_install, dim3(ig, K), dim3(256), 0, s, refs, dp, scan_blocks * SCAN_WAVES, scan_tiles);
     }
     HIP_CHECK(hipGetLastError());
