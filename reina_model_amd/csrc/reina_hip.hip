@@ -488,6 +488,7 @@ int reina_group_create(reina_engine_t **engines, uint32_t n, reina_group_t **out
         g->h_refs[k].history_base = nullptr;
     }
     HIP_CHECK(hipMalloc(&g->d_refs, sizeof(MemberRef) * n));
+    HIP_CHECK(hipMemcpy(g->d_refs, g->h_refs.data(), sizeof(MemberRef) * n, hipMemcpyHostToDevice));   // (table broadcasts may precede the first run)
     *out = g;
     return REINA_OK;
 }
@@ -499,12 +500,47 @@ int reina_group_destroy(reina_group_t *g) {
     return REINA_OK;
 }
 
+// the table-dependent parts of DevParams: [nrc, iot_mask) and [n_ranges, end)
+#define DP_TAB0_BEGIN offsetof(DevParams, nrc)
+#define DP_TAB0_END offsetof(DevParams, iot_mask)
+#define DP_TAB1_BEGIN offsetof(DevParams, n_ranges)
+static_assert(DP_TAB0_BEGIN % 4 == 0 && DP_TAB0_END % 4 == 0 && DP_TAB1_BEGIN % 4 == 0, "word copies");
+
+// member 0's freshly uploaded tables, device to device, into every other member of the group
+__global__ __launch_bounds__(256) void k_group_tables(const MemberRef *refs) {
+    const MemberRef &src = refs[0], &dst = refs[blockIdx.y + 1];
+    const uint32_t stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        const uint32_t *s_ = reinterpret_cast<const uint32_t *>(src.T);
+        uint32_t *d_ = reinterpret_cast<uint32_t *>(const_cast<Tables *>(dst.T));
+        for (uint32_t k = first; k < sizeof(Tables) / 4; k += stride) d_[k] = s_[k];
+    }
+    const uint32_t *sp = reinterpret_cast<const uint32_t *>(src.P);
+    uint32_t *dp_ = reinterpret_cast<uint32_t *>(const_cast<DevParams *>(dst.P));
+    for (uint32_t k = DP_TAB0_BEGIN / 4 + first; k < DP_TAB0_END / 4; k += stride) dp_[k] = sp[k];
+    for (uint32_t k = DP_TAB1_BEGIN / 4 + first; k < sizeof(DevParams) / 4; k += stride) dp_[k] = sp[k];
+}
+
 int reina_group_upload_contact_tables(reina_group_t *g, const reina_contact_tables_t *t, void *stream) {
     if (!g) return REINA_E_INVALID;
-    for (auto m : g->members) {
-        int rc = reina_upload_contact_tables(m, t, stream);
-        if (rc) return rc;
+    // the members sample from identical tables: one transfer from the host (member 0), one device-to-device
+    // broadcast to the others -- two launches whatever the size of the group
+    reina_engine_t *e0 = g->members[0];
+    int rc = reina_upload_contact_tables(e0, t, stream);
+    if (rc) return rc;
+    const uint32_t K = (uint32_t)g->members.size();
+    if (K == 1) return REINA_OK;
+    for (uint32_t k = 1; k < K; k++) {   // host mirrors follow
+        reina_engine_t *m = g->members[k];
+        std::memcpy(reinterpret_cast<char *>(&m->h_params) + DP_TAB0_BEGIN, reinterpret_cast<const char *>(&e0->h_params) + DP_TAB0_BEGIN,
+                    DP_TAB0_END - DP_TAB0_BEGIN);
+        std::memcpy(reinterpret_cast<char *>(&m->h_params) + DP_TAB1_BEGIN, reinterpret_cast<const char *>(&e0->h_params) + DP_TAB1_BEGIN,
+                    sizeof(DevParams) - DP_TAB1_BEGIN);
+        std::memcpy(&m->h_tables, &e0->h_tables, sizeof(Tables));
+        m->uniform_meta = e0->uniform_meta;
     }
+    hipLaunchKernelGGL(k_group_tables, dim3(32, K - 1), dim3(256), 0, (hipStream_t)stream, g->d_refs);
+    HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
 
