@@ -206,6 +206,15 @@ class TorchAllocator:
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
     def to_host(self, t):
+        # histories (a few MB per run, tens of MB per engine group) come back through pinned memory: the
+        # pageable path runs at a fraction of the link rate and is part of every run()'s wall time.
+        # (PyTorch's caching host allocator keeps the pinned block for the next run.)
+        nbytes = t.numel() * t.element_size()
+        if (1 << 18) <= nbytes <= (1 << 29):
+            h = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            self.torch.cuda.current_stream(self.device).synchronize()
+            return h.numpy()
         return t.cpu().numpy()
 
 
