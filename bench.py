@@ -366,40 +366,39 @@ def main():
                     out['roofline']['traffic'] = tj[key]
             except Exception:
                 pass
-        if not a.no_large and world == 1 and not a.agents:
-            vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.large_agents)
-            dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, preheat=min(a.preheat_days, 120), stride=a.time_every)
-            out['large'] = {
-                'workload': 'synthetic %d agents (BASELINE configs[2]), default scenario scaled, %d days' % (nl, a.steps),
+        def extra(key, fn):
+            # the additional workloads must not take the headline line down with them
+            try:
+                out[key] = fn()
+            except Exception as e:   # noqa: BLE001 -- reported in the line itself
+                out[key] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+
+        def sized_line(n_agents_cfg, label, preheat, preheat_runs):
+            vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), n_agents_cfg)
+            dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, preheat=preheat,
+                                             stride=a.time_every, preheat_runs=preheat_runs)
+            line = {
+                'workload': 'synthetic %d agents (%s), default scenario scaled, %d days' % (nl, label, a.steps),
                 'value': round(nl * a.steps / dtl, 1), 'unit': 'agent-days/s',
                 'ms_per_step': round(dtl * 1000 / a.steps, 6),
                 'roofline': roofline_obj(nl, a.steps, profl, statsl, a.time_every, dtl * 1000 / a.steps),
                 'final_all_infected': statsl['final_all_infected'],
             }
             try:   # PMC traffic of the same workload (profiles/traffic.json, collected in separate --pmc passes)
-                out['large']['roofline']['traffic'] = json.load(open(traffic_file)).get(str(a.large_agents))
+                line['roofline']['traffic'] = json.load(open(traffic_file)).get(str(n_agents_cfg))
             except Exception:
                 pass
+            return line
+
+        if not a.no_large and world == 1 and not a.agents:
+            extra('large', lambda: sized_line(a.large_agents, 'BASELINE configs[2]', min(a.preheat_days, 120), 2))
             if a.xlarge_agents:
                 # SURVEY 8d's second point: a hot array (0.8 GB) that no cache level holds
-                vx, agesx = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.xlarge_agents)
-                dtx, profx, statsx, nx = run_gpu(vx, agesx, a.seed, a.steps, a.warmup, device, preheat=min(a.preheat_days, 30),
-                                                 stride=a.time_every, preheat_runs=1)
-                out['xlarge'] = {
-                    'workload': 'synthetic %d agents (SURVEY 8d: HBM-resident regime), default scenario scaled, %d days' % (nx, a.steps),
-                    'value': round(nx * a.steps / dtx, 1), 'unit': 'agent-days/s',
-                    'ms_per_step': round(dtx * 1000 / a.steps, 6),
-                    'roofline': roofline_obj(nx, a.steps, profx, statsx, a.time_every, dtx * 1000 / a.steps),
-                    'final_all_infected': statsx['final_all_infected'],
-                }
-                try:
-                    out['xlarge']['roofline']['traffic'] = json.load(open(traffic_file)).get(str(a.xlarge_agents))
-                except Exception:
-                    pass
+                extra('xlarge', lambda: sized_line(a.xlarge_agents, 'SURVEY 8d: HBM-resident regime', min(a.preheat_days, 30), 1))
         if large_sharded is not None:
             out['large'] = large_sharded
         if not a.no_ensemble and world == 1 and not a.agents:
-            out['ensemble'] = ensemble_line(a.ensemble_seeds, a.steps, device)
+            extra('ensemble', lambda: ensemble_line(a.ensemble_seeds, a.steps, device))
         if not a.no_cpu and world == 1:   # the CPU baseline is an N=1 figure
             hus = datasets.get_population_for_area()
             out['cpu_baseline'] = cpu_baseline(copy.deepcopy(VARIABLE_DEFAULTS), hus, a.seed, a.cpu_days)
