@@ -278,12 +278,27 @@ def test_engine_group_equals_individual_members():
         _assert_state_equal(members[m], cpu)
     # members stay usable on their own after the group is gone (the planner keeps the scenario's
     # host-side state, so the continuation plan comes from it)
+    # (member 0 took the group's contact tables from the host, the others by device-to-device broadcast)
     more = planner.make_plan(5)
-    h1 = members[0].run_plan(more)
-    cpu0 = simulation.make_context(v, age_counts=ages, seed=seeds[0], interventions=ivs,
-                                   engine_factory=par_backend.par_engine_factory)
-    cpu0.run(days)
-    assert np.array_equal(h1, cpu0.run(5))
+    for m in (0, len(seeds) - 1):
+        h1 = members[m].run_plan(more)
+        cpu0 = simulation.make_context(v, age_counts=ages, seed=seeds[m], interventions=ivs,
+                                       engine_factory=par_backend.par_engine_factory)
+        cpu0.run(days)
+        assert np.array_equal(h1, cpu0.run(5)), m
+
+
+def test_history_readback_paths_agree():
+    """TorchAllocator.to_host: small and huge tensors through the pageable copy, histories through pinned
+    memory -- the same bytes either way."""
+    import torch
+    a = eng.TorchAllocator('cuda:0')
+    for n in (1000, (1 << 16) - 3, (1 << 16) + 5, 3_000_000):
+        t = torch.arange(n, dtype=torch.int32, device='cuda:0') * 7 - 11
+        h = a.to_host(t)
+        assert h.dtype == np.int32 and np.array_equal(h, t.cpu().numpy())
+        h[0] = 5    # the caller owns what it gets
+        assert int(t[0].item()) == -11
 
 
 def test_run_ensemble_batched_equals_threaded():
