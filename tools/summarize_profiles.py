@@ -21,10 +21,11 @@ os.makedirs(P, exist_ok=True)
 traffic = {}
 pmc_rows = [['config', 'counter', 'launches', 'mean_KB', 'min_KB', 'max_KB']]
 for cfg, key in (('hus', 'hus'), ('50m', '50000000'), ('200m', '200000000')):
-    st = glob.glob(os.path.join(G, '%s_trace_%s' % (tag, cfg), '*', '*kernel_stats.csv'))
+    newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime, reverse=True)   # several collections may share a tag
+    st = newest(os.path.join(G, '%s_trace_%s' % (tag, cfg), '*', '*kernel_stats.csv'))
     if st:
         shutil.copy(st[0], os.path.join(P, '%s_kernel_stats_%s.csv' % (tag, cfg)))
-    tr = glob.glob(os.path.join(G, '%s_trace_%s' % (tag, cfg), '*', '*kernel_trace.csv'))
+    tr = [t for t in newest(os.path.join(G, '%s_trace_%s' % (tag, cfg), '*', '*kernel_trace.csv')) if os.path.getsize(t) > 100000]
     if tr:
         rows = list(csv.DictReader(open(tr[0])))
         # the timed region = from the 365th-last k_scan launch on (preheat and warm-up runs come before)
@@ -43,7 +44,7 @@ for cfg, key in (('hus', 'hus'), ('50m', '50000000'), ('200m', '200000000')):
     tot = 0.0
     ok = True
     for kind, cname, mult in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE', 1.0)):
-        f = glob.glob(os.path.join(G, '%s_%s_%s' % (tag, kind, cfg), '*', '*counter_collection.csv'))
+        f = newest(os.path.join(G, '%s_%s_%s' % (tag, kind, cfg), '*', '*counter_collection.csv'))
         if not f:
             ok = False
             continue
