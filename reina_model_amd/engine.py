@@ -253,6 +253,8 @@ class Engine:
         self._keep = []
 
     def _check(self, rc, what):
+        if what != 'read_counters':
+            self._prefetched = False      # anything launched since makes a prefetched counter block stale
         if rc != 0:
             msg = self.f['last_error']()
             raise EngineError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
@@ -311,7 +313,26 @@ class Engine:
         """`arr` is a ctypes (Day * n) array that may be shared between engines."""
         self._check(self.f['run_days_hist'](self._h, arr, n, history_ptr, self.alloc.stream()), 'run_days_hist')
 
+    def prefetch_counters(self):
+        """Queue the copy of the counter block behind what has been launched so far (pinned memory, no
+        wait).  The reference's loop alternates iterate() and generate_state(): with the copy already in
+        flight, the day runs on the GPU while the host is still turning the previous state into its
+        dictionaries, and generate_state() finds the block waiting instead of draining the stream."""
+        t = getattr(self.alloc, 'torch', None)
+        if t is None:
+            return
+        if getattr(self, '_pf_buf', None) is None:
+            self._pf_buf = t.empty(COUNTER_WORDS, dtype=t.int32, pin_memory=True)
+            self._pf_ev = t.cuda.Event()
+        self._pf_buf.copy_(self.tensors['counters'], non_blocking=True)
+        self._pf_ev.record(t.cuda.current_stream(self.alloc.device))
+        self._prefetched = True
+
     def read_counters(self):
+        if getattr(self, '_prefetched', False):
+            self._prefetched = False
+            self._pf_ev.synchronize()
+            return self._pf_buf.numpy().copy()
         out = np.zeros(COUNTER_WORDS, dtype=np.int32)
         self._check(self.f['read_counters'](self._h, out.ctypes.data, self.alloc.stream()), 'read_counters')
         return out
@@ -366,6 +387,8 @@ class EngineGroup:
         hp = None
         if history_ptrs is not None:
             hp = (ctypes.c_void_p * len(self.engines))(*[int(p) for p in history_ptrs])
+        for e in self.engines:
+            e._prefetched = False
         self.engines[0]._check(self.f['group_run_days'](self._h, arr, n, hp, self.alloc.stream()), 'group_run_days')
 
 

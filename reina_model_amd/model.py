@@ -518,6 +518,8 @@ class Context:
             self._upload_tables()
         self._step(d)
         self.day += 1
+        if self.n_shards == 1 and not self.always_collective:
+            self.engine.prefetch_counters()   # the next generate_state() finds them on the host
 
     def make_plan(self, days):
         """Host part of `days` consecutive days, done once: the intervention schedule turned into
