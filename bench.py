@@ -270,6 +270,7 @@ def main():
     ap.add_argument('--no-ensemble', action='store_true')
     ap.add_argument('--ensemble-seeds', type=int, default=32)
     ap.add_argument('--cpu-all-cores-days', type=int, default=120)
+    ap.add_argument('--cpu-max-procs', type=int, default=64, help='concurrent CPU simulations of the all-cores baseline')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--time-every', type=int, default=8,
                     help='k_scan launches carry HIP event timestamps on every k-th day of the timed region')
@@ -282,7 +283,7 @@ def main():
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
     cpu_all = None
     if world_env == 1 and not a.no_cpu and not a.agents and a.cpu_all_cores_days > 0:
-        cpu_all = CpuAllCores(a.cpu_all_cores_days)   # helper spawned before anything initialises the GPU; runs last
+        cpu_all = CpuAllCores(a.cpu_all_cores_days, a.cpu_max_procs)   # helper spawned before anything initialises the GPU; runs last
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
