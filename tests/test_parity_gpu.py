@@ -488,3 +488,29 @@ def test_more_bed_events_in_a_day_than_one_pass_holds():
     assert c['all_infected'].sum() > 10_000_000 and c['dead'].sum() > 50_000
     peak = int(gpu.engine.alloc.to_host(gpu.engine.tensors['control'])[eng.L_HOSP_PEAK])
     assert peak > 2 * 16384, peak
+
+
+def test_large_engine_group_geometry():
+    """64 members: each gets 3 contact workgroups, 8 k_install workgroups and a slice count rounded to a
+    multiple of its contact waves (reina_hip.hip: scan_blocks_for / con_blocks_for), tables arrive by
+    broadcast -- sampled members == oracle B run alone, bit for bit."""
+    import par_backend
+    from reina_model_amd import ensemble
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=40, icu_units=5)
+    ages = datasets.scaled_population(70000)
+    ivs = [['import-infections', '2020-02-19', 300], ['test-all-with-symptoms', '2020-02-20'], ['test-with-contact-tracing', '2020-03-05', 40],
+           ['limit-mobility', '2020-03-01', 30], ['limit-mobility', '2020-03-12', 50, 0, 70, 'leisure']]
+    days, K = 60, 64
+    planner = simulation.make_context(v, age_counts=ages, seed=0, interventions=ivs)
+    plan = planner.make_plan(days)
+    members = [simulation.make_context(v, age_counts=ages, seed=900 + s, interventions=ivs) for s in range(K)]
+    hist = ensemble.run_group_plan(members, plan)
+    for m in (0, 1, 31, 63):
+        cpu = simulation.make_context(v, age_counts=ages, seed=900 + m, interventions=ivs,
+                                      engine_factory=par_backend.par_engine_factory)
+        assert np.array_equal(hist[m], cpu.run(days)), m
+        _assert_state_equal(members[m], cpu)
+    A = eng.MAX_AGES
+    i = eng.C_NAMES.index('all_infected')
+    assert hist[:, -1, i * A:(i + 1) * A].sum(axis=1).min() > 300
