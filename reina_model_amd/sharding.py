@@ -94,9 +94,10 @@ class TorchComm:
                 import sys
                 print('reina: direct RCCL communicator unavailable (%s); using torch.distributed' % e, file=sys.stderr)
                 self.direct = None
-            if self.world > 1:
+            if True:
                 # every rank must take the same route: one rank on torch.distributed while the others sit in
-                # the direct communicator's all-reduce would hang the day loop
+                # the direct communicator's all-reduce would hang the day loop (also run with a single rank,
+                # so that the one-GPU test box exercises these lines)
                 ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32,
                                   device=torch.device('cuda', torch.cuda.current_device()))
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
