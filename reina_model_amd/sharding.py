@@ -52,8 +52,8 @@ class DirectRccl:
             if rc != 0:
                 raise RuntimeError('ncclGetUniqueId failed: %d' % rc)
         box = [bytes(bytearray(uid)) if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        # (also with a single rank: the one-GPU test box then exercises the call)
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ctypes.memmove(ctypes.byref(uid), box[0], 128)
         self.comm = ctypes.c_void_p()
         self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
