@@ -1,32 +1,51 @@
 #!/usr/bin/env python3
 """bench.py -- agent-days/s of the MI355X-native day step, with roofline and CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--agents A] [--no-cpu] [--no-large]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--agents A] [--no-cpu] [--no-sizes] [--no-ensemble]
 
 A "step" is one simulated day (Context.iterate of the reference, cythonsim/main.pyx:2011-2018)
 over the whole population.  At N=1 the workload is BASELINE.json configs[1]: the HUS population
-(1 685 983 agents, real age structure + FI contact matrix), default scenario, K=365 days.
-W warm-up days are simulated first (untimed), then exactly K days are timed between
-barrier + torch.cuda.synchronize() pairs; rank 0 prints ONE JSON line.
+(1 685 983 agents, real age structure + FI contact matrix), default scenario.  W warm-up days are
+simulated first (untimed), then exactly K days are timed between barrier + torch.cuda.synchronize()
+pairs; rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU and starts
+the N ranks itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 ...` as a child process), relays the child's output and exits with its code.  Under
+torchrun (WORLD_SIZE set) it is one rank: the population is `--agents` (default 1 685 983) agents PER
+GPU, age-stratified shards, one 8 KB RCCL all-reduce of infection pressure per day ("scaling": "weak").
 
 Inputs are resident in HBM when the timed region starts (state tensors, tables); per-day host
 work inside the region is the intervention schedule -> day descriptors (+ a 100 KB table upload
 on the 11 days the mobility factors change), exactly what the reference's iterate() does on host.
 
-Extra objects on the line:
-  roofline     dominant kernel k_scan: algorithmic bytes per launch (4 B hot word read per agent +
-               4 B written back per infected agent) / mean launch duration
-               from HIP events recorded on the launch stream inside the timed region (every --time-every-th day), vs 8 TB/s.
-  cpu_baseline the sequential C oracle (oracle/reina_seq.c, bit-exact vs the reference cythonsim)
-               timed on one host core on a bounded sample (first days of the same workload).
-  ensemble     BASELINE config 5 shape: 32 seeds of the HUS scenario as one engine group.
-  large        the same measurement on BASELINE configs[2] (synthetic 50 M agents, HUS age shape,
-               beds/ICU/imports scaled) -- the HBM-resident regime the roofline is meant for.
+Objects on the line:
+  roofline       THE DAY against HBM: achieved = sum over the timed days of
+                 B_alg(day) = 4 N + 4 N_inf + 4 C + 12 I_new bytes / wall time of the timed region; frac =
+                 achieved / 8 TB/s.  `kernels`: every kernel of the day with its mean launch duration from
+                 HIP events on the launch stream inside the timed region (one kind of kernel per profiled
+                 day, the kinds taking turns), its share of the day, and -- where the kernel has
+                 algorithmic bytes of its own -- bytes per launch and achieved GB/s.  `dominant_kernel`
+                 names the streaming kernel k_scan with its per-launch figure.  `traffic`: HBM bytes per
+                 day from PMC counters (profiles/traffic.json: separate rocprofv3 --pmc passes, FETCH_SIZE
+                 doubled per MI355X_MICROARCH.md); only reported when that file was collected on the very
+                 library binary being timed (sha256 match), else null.
+  full_scenario  the same figures over the whole 365-day default scenario (epidemic peak included) for HUS,
+                 5 x 10^7 (configs[2]), 10^8 (BASELINE's "100 M agents") and 2 x 10^8 agents (SURVEY 8d's
+                 HBM-resident point) -- a short --steps window right after the start is all quiet days.
+  ensemble       BASELINE config 5 per-GPU batch: 128 seeds of the HUS scenario as one engine group.
+  cpu_baseline   the sequential C restatement of cythonsim (oracle/reina_seq.c, bit-exact vs the reference)
+                 on one host core over THE SAME day window (W untimed, K timed days), repeated over seeds
+                 until about 10 s of timed work; `all_cores`: one simulation per core, first 120 days each
+                 (a different window: labelled).
 """
 import argparse
 import copy
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +54,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HUS_AGENTS = 1685983
+DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_scan', 'k_hosp_contacts', 'k_remote', 'k_install')
 
 
 def scaled_scenario(variables, total_agents):
@@ -66,7 +87,14 @@ def _shared_comm(sharding):
     return _COMM[0]
 
 
-def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=1, preheat_runs=2):
+def stride_for(steps, time_every):
+    """profiled days: one kind of kernel per profiled day; short runs profile every day (stride 4)"""
+    if time_every:
+        return max(4, int(time_every) // 4 * 4)
+    return 4 if steps < 64 else 8 if steps < 160 else 16
+
+
+def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=16, preheat_runs=2):
     import numpy as np
     import torch
     from reina_model_amd import engine as eng
@@ -80,7 +108,7 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
         pre.engine.profile_enable(stride)
         pre.run(preheat, record_history=True)
         pre.synchronize()
-        pre.engine.profile_read()
+        pre.engine.profile_read_kernels()
         del pre
     ctx = simulation.make_context(variables, age_counts=ages, seed=seed, device=device, comm=comm)
     # the event-timed launch path is switched on BEFORE the warm-up so its one-time costs (event
@@ -89,7 +117,7 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
     if warmup:
         ctx.run(warmup, record_history=False)
     ctx.synchronize()
-    ctx.engine.profile_read()  # discard the warm-up launches
+    ctx.engine.profile_read_kernels()  # discard the warm-up launches
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -99,61 +127,118 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
-    prof = ctx.engine.profile_read()
+    prof = ctx.engine.profile_read_kernels()
     ctx.engine.profile_enable(False)
-    if comm is not None:
-        hist = hist // 1  # already the global (summed) history on every rank
     A = eng.MAX_AGES
-    inf = hist[:, eng.C_NAMES.index('infected') * A:(eng.C_NAMES.index('infected') + 1) * A].sum(axis=1)
+
+    def tot(name):
+        i = eng.C_NAMES.index(name)
+        return hist[:, i * A:(i + 1) * A].sum(axis=1).astype(np.float64)
+
+    world = comm.world if comm is not None else 1
+    inf = tot('infected') / world                      # (sharded: the history is global, a launch streams one shard)
     sc = hist[:, eng.C_NR * A:]
-    timed = (np.arange(steps) + warmup) % stride == 0   # the days whose scan launch carried timestamps
+    days = np.arange(steps) + warmup
+    contacts = sc[:, eng.S_EXPOSED_PER_DAY].astype(np.float64) / world
+    # row d is the state BEFORE day d ran: day d's own new infections / contacts are in row d + 1
+    new_inf = tot('new_infections') / world
     stats = dict(
-        mean_infected=float(inf[timed].mean() if timed.any() else inf.mean()),
-        mean_infected_all_days=float(inf.mean()),
-        contacts=float(sc[:, eng.S_EXPOSED_PER_DAY].sum()),
-        new_infections=float(hist[:, eng.C_NAMES.index('new_infections') * A:(eng.C_NAMES.index('new_infections') + 1) * A].sum()),
-        final_all_infected=int(hist[-1, eng.C_NAMES.index('all_infected') * A:(eng.C_NAMES.index('all_infected') + 1) * A].sum()),
+        infected_on_scan_days=float(inf[days % stride == 0].mean() if (days % stride == 0).any() else inf.mean()),
+        mean_infected=float(inf.mean()),
+        contacts_per_day=float(contacts[1:].mean() if steps > 1 else contacts.mean()),
+        contacts_on_contact_days=float(contacts[1:][(days[:-1] % stride) == stride // 2].mean()
+                                       if steps > 1 and ((days[:-1] % stride) == stride // 2).any() else contacts.mean()),
+        new_infections_per_day=float(new_inf[1:].mean() if steps > 1 else new_inf.mean()),
+        final_all_infected=int(tot('all_infected')[-1]),
+        peak_infected=int(tot('infected').max()),
     )
-    if comm is not None:
-        stats['mean_infected'] /= comm.world  # per-shard share for the per-launch byte count
-        stats['mean_infected_all_days'] /= comm.world
-    return t1 - t0, prof, stats, ctx.total_people
+    rccl_world = None
+    if comm is not None and getattr(comm, 'direct', None) is not None:
+        rccl_world = comm.direct.count()
+    return dict(dt=t1 - t0, prof=prof, stats=stats, n_local=ctx.total_people, rccl_world=rccl_world)
 
 
-def roofline_obj(n_agents, steps, prof, stats, stride=1, ms_per_step=None):
-    # algorithmic bytes of one k_scan launch: every agent's 4-byte hot word read once, the hot
-    # word of every infected agent written back (the 4*N + 4*N_inf terms)
-    bytes_per_launch = 4.0 * n_agents + 4.0 * stats['mean_infected']
-    launches = max(1, int(prof['scan_launches']))
-    ms = prof['scan_ms_total'] / launches
-    achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    day_bytes = (4.0 * n_agents * steps + 4.0 * stats['mean_infected_all_days'] * steps
-                 + 4.0 * stats['contacts'] + 12.0 * stats['new_infections']) / steps
-    extra = {}
-    if ms_per_step:
-        # the whole day against the same roofline (sum of B_alg / wall): small populations are
-        # latency-bound, this is the honest figure next to the streaming kernel's
-        extra = dict(day_achieved=round(day_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                     day_frac=round(day_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
-    return dict(bound='hbm', kernel='k_scan', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
-                frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
-                bytes_per_launch=bytes_per_launch, avg_launch_ms=round(ms, 6), launches=launches,
-                launches_note='timestamped launches: every %d-th day of the timed region' % stride,
-                day_algorithmic_bytes=round(day_bytes, 1), **extra)
+def lib_sha256():
+    from reina_model_amd import engine as eng
+    h = hashlib.sha256()
+    with open(eng.HIP_LIB_PATH, 'rb') as f:
+        h.update(f.read())
+    return h.hexdigest()
 
 
-def cpu_baseline(variables, ages, seed, days):
+def traffic_for(key):
+    """HBM bytes per day from the PMC passes, only if collected on this very binary"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    except Exception:
+        return None, 'no profiles/traffic.json'
+    if tj.get('lib_sha256') != lib_sha256():
+        return None, 'profiles/traffic.json was collected on another binary (sha256 %s..., commit %s): not reported' % (
+            str(tj.get('lib_sha256'))[:12], tj.get('commit'))
+    val = tj.get('per_day_bytes', {}).get(key)
+    return val, 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the kernels of a day, mean over the scenario; commit %s' % tj.get('commit')
+
+
+def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
+    """day-level roofline + every kernel's HIP-event time"""
+    st, prof = res['stats'], res['prof']
+    ms_per_step = res['dt'] * 1000 / steps
+    day_bytes = 4.0 * n_agents + 4.0 * st['mean_infected'] + 4.0 * st['contacts_per_day'] + 12.0 * st['new_infections_per_day']
+    achieved = day_bytes / (ms_per_step * 1e-3) / 1e9
+    alg = {   # algorithmic bytes per launch of the kernels that own a term of B_alg
+        'k_scan': 4.0 * n_agents + 4.0 * st['infected_on_scan_days'],
+        'k_hosp_contacts': 4.0 * st['contacts_on_contact_days'],
+        'k_install': 12.0 * st['new_infections_per_day'],
+    }
+    kernels, ksum = {}, 0.0
+    for k in DAY_KERNELS:
+        ms, n = prof.get(k, (0.0, 0))
+        if not n:
+            continue
+        us = ms * 1000.0 / n
+        ent = dict(avg_launch_us=round(us, 3), timed_launches=n)
+        if k in alg:
+            ent['algorithmic_bytes_per_launch'] = round(alg[k], 1)
+            ent['achieved_GBs'] = round(alg[k] / (us * 1e-6) / 1e9, 2)
+            ent['frac_of_hbm_peak'] = round(alg[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        kernels[k] = ent
+    every_day = [k for k in ('k_open', 'k_scan', 'k_hosp_contacts', 'k_install') if k in kernels]
+    ksum = sum(kernels[k]['avg_launch_us'] for k in every_day)
+    for k in every_day:
+        kernels[k]['share_of_kernel_time'] = round(kernels[k]['avg_launch_us'] / ksum, 4) if ksum else None
+    out = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5),
+               traffic=None, scope='whole day: sum of B_alg over the timed days / wall time of the timed region (SURVEY.md 8d)',
+               algorithmic_bytes_per_day=round(day_bytes, 1),
+               algorithmic_bytes_formula='4*N + 4*N_infected + 4*contacts + 12*new_infections (per day, means over the timed days)',
+               ms_per_step=round(ms_per_step, 6), kernel_us_per_day=round(ksum, 3), kernels=kernels,
+               kernel_timing='HIP events (start/stop of the dispatch packet, launch stream) inside the timed region; on a profiled day '
+                             'one kind of kernel is timed: stride %d days per kind' % stride)
+    if 'k_scan' in kernels:
+        out['dominant_kernel'] = dict(name='k_scan', **kernels['k_scan'])
+    if traffic_key is not None:
+        out['traffic'], out['traffic_note'] = traffic_for(traffic_key)
+    return out
+
+
+def cpu_baseline(variables, ages, seed, steps, warmup, budget_s=10.0, max_runs=16):
+    """oracle A (sequential C restatement, bit-exact vs the reference) on one core over the SAME window"""
     from oracle import seq_oracle
     import numpy as np
-    ctx = seq_oracle.make_context(variables, ages, seed)
-    t0 = time.perf_counter()
-    for _ in range(days):
-        ctx.iterate()
-    dt = time.perf_counter() - t0
     n = int(np.asarray(ages).sum())
-    return dict(value=round(n * days / dt, 1), unit='agent-days/s', cores=1, kind='port',
-                sample='sequential C restatement of cythonsim (bit-exact vs reference goldens), '
-                       'HUS %d agents, first %d days of the default scenario, 1 thread, %.1f s' % (n, days, dt))
+    timed, runs = 0.0, 0
+    while timed < budget_s and runs < max_runs:
+        ctx = seq_oracle.make_context(variables, ages, seed + runs)
+        for _ in range(warmup):
+            ctx.iterate()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.iterate()
+        timed += time.perf_counter() - t0
+        runs += 1
+    return dict(value=round(n * steps * runs / timed, 1), unit='agent-days/s', cores=1, kind='port',
+                sample='sequential C restatement of cythonsim (bit-exact vs reference goldens), HUS %d agents, the same window as '
+                       'the GPU line (%d untimed + %d timed days of the default scenario), %d run(s) with seeds %d.., 1 thread, '
+                       '%.1f s timed' % (n, warmup, steps, runs, seed, timed))
 
 
 _CPU_WORKER = r"""
@@ -202,7 +287,6 @@ class CpuAllCores:
     so that the all-core load cannot disturb them."""
 
     def __init__(self, days, max_procs=64):
-        import subprocess
         import tempfile
         self.days = days
         self.procs = min(os.cpu_count() or 1, max_procs)
@@ -226,32 +310,65 @@ class CpuAllCores:
         if not spans:
             return None
         wall = max(b for _, b in spans) - min(a for a, _ in spans)
-        n = 1685983
-        return dict(value=round(n * self.days * len(spans) / wall, 1), unit='agent-days/s', cores=len(spans), kind='port',
+        return dict(value=round(HUS_AGENTS * self.days * len(spans) / wall, 1), unit='agent-days/s', cores=len(spans), kind='port',
                     sample='%d concurrent sequential simulations (one per core, cores capped at %d), HUS %d agents, '
-                           'first %d days each, %.1f s wall' % (len(spans), self.max_procs, n, self.days, wall))
+                           'FIRST %d DAYS each (not the GPU line\'s window), %.1f s wall' % (
+                               len(spans), self.max_procs, HUS_AGENTS, self.days, wall))
 
 
-def ensemble_line(seeds, days, device):
-    """BASELINE config 5 shape: a Monte-Carlo ensemble of HUS simulations on one GPU, stepped as an
-    engine group (one launch per phase for all members)."""
+def ensemble_line(seeds, days, device, dist=None):
+    """BASELINE config 5: a Monte-Carlo ensemble of HUS simulations stepped as an engine group (one launch
+    per phase for all members); 128 seeds = the per-GPU batch of the 1024-seed configuration.  Over several
+    ranks: replicas only, every rank runs its own `seeds` members, no data-path collective."""
     import torch
     from reina_model_amd import datasets, ensemble, simulation
     from reina_model_amd.variables import VARIABLE_DEFAULTS
     v = copy.deepcopy(VARIABLE_DEFAULTS)
     ages = datasets.get_population_for_area()
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
     planner = simulation.make_context(v, age_counts=ages, seed=0, device=device)
     plan = planner.make_plan(days)
-    members = [simulation.make_context(v, age_counts=ages, seed=100 + k, device=device) for k in range(seeds)]
+    members = [simulation.make_context(v, age_counts=ages, seed=100 + rank * seeds + k, device=device) for k in range(seeds)]
+    members[0].engine.profile_enable(16)
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ensemble.run_group_plan(members, plan)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     dt = time.perf_counter() - t0
+    prof = members[0].engine.profile_read_kernels()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     n = int(ages.sum())
-    return dict(workload='%d seeds x HUS %d agents x %d days, one engine group' % (seeds, n, days),
-                value=round(seeds * n * days / dt, 1), unit='agent-days/s', ms_per_step=round(dt * 1000 / days, 6),
-                members=seeds)
+    return dict(workload='%d seeds x HUS %d agents x %d days per GPU, one engine group per GPU (config 5: replicas only)' % (seeds, n, days),
+                value=round(world * seeds * n * days / dt, 1), unit='agent-days/s', ms_per_step=round(dt * 1000 / days, 6),
+                members_per_gpu=seeds, n_gpus=world,
+                kernels={k: dict(avg_launch_us=round(ms * 1000 / c, 2), timed_launches=c) for k, (ms, c) in prof.items() if c})
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process tree before this
+    process has made any GPU call (it never makes one), relay the output, exit with the child's code."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -261,25 +378,27 @@ def main():
     ap.add_argument('--steps', type=int, default=365)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--agents', type=int, default=0, help='synthetic population per GPU (0 = HUS)')
-    ap.add_argument('--large-agents', type=int, default=50_000_000)
-    ap.add_argument('--xlarge-agents', type=int, default=200_000_000,
-                    help='SURVEY 8d: a population well past the 256 MB Infinity Cache (0 = skip)')
-    ap.add_argument('--cpu-days', type=int, default=120)
+    ap.add_argument('--sizes', default='50000000,100000000,200000000',
+                    help='synthetic populations of the full_scenario object (HUS is always there)')
+    ap.add_argument('--large-agents', type=int, default=50_000_000, help='N > 1: agents per GPU of the `large` object')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-sizes', action='store_true', help='skip the full_scenario object')
     ap.add_argument('--no-large', action='store_true')
     ap.add_argument('--no-ensemble', action='store_true')
-    ap.add_argument('--ensemble-seeds', type=int, default=32)
+    ap.add_argument('--ensemble-seeds', type=int, default=128)
     ap.add_argument('--cpu-all-cores-days', type=int, default=120)
     ap.add_argument('--cpu-max-procs', type=int, default=64, help='concurrent CPU simulations of the all-cores baseline')
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--time-every', type=int, default=8,
-                    help='k_scan launches carry HIP event timestamps on every k-th day of the timed region')
+    ap.add_argument('--time-every', type=int, default=0,
+                    help='each kind of kernel carries HIP event timestamps on every k-th day (0: 4 / 8 / 16 by run length)')
     ap.add_argument('--preheat-days', type=int, default=365,
                     help='days of a throw-away simulation run before the measured one (GPU clocks, one-time costs)')
     a = ap.parse_args()
-    if a.steps < 8 * a.time_every:      # short runs: at least ~8 timestamped launches, every day if need be
-        a.time_every = max(1, a.steps // 8)
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a.gpus))
+
+    stride = stride_for(a.steps, a.time_every)
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
     cpu_all = None
     if world_env == 1 and not a.no_cpu and not a.agents and a.cpu_all_cores_days > 0:
@@ -305,104 +424,107 @@ def main():
             dist.init_process_group(backend)
     device = 'cuda:%d' % local_rank
 
+    import numpy as np
     from reina_model_amd import datasets
     from reina_model_amd.variables import VARIABLE_DEFAULTS
     v = copy.deepcopy(VARIABLE_DEFAULTS)
-    per_gpu = a.agents if a.agents else 1685983
+    per_gpu = a.agents if a.agents else HUS_AGENTS
     if a.agents or world > 1:
         # weak scaling: the GLOBAL population is per_gpu x world agents, sharded over the ranks
         # (BASELINE configs[3] shape: HUS age structure, beds / ICU / imports scaled with it)
         v, ages = scaled_scenario(v, per_gpu * world)
-        workload = 'synthetic %d agents (%d per GPU; HUS age structure + FI contact matrix, beds/ICU/imports scaled), default scenario, %d days' % (per_gpu * world, per_gpu, a.steps)
+        workload = 'synthetic %d agents (%d per GPU; HUS age structure + FI contact matrix, beds/ICU/imports scaled), default scenario, days %d..%d' % (
+            per_gpu * world, per_gpu, a.warmup, a.warmup + a.steps - 1)
+        traffic_key = str(a.agents) if world == 1 else None
     else:
         ages = datasets.get_population_for_area()
-        workload = 'HUS 1685983 agents, default scenario (variables.py:227-435), %d days' % a.steps
+        workload = 'HUS %d agents (BASELINE configs[1]), default scenario (variables.py:227-435), days %d..%d' % (
+            HUS_AGENTS, a.warmup, a.warmup + a.steps - 1)
+        traffic_key = 'hus'
 
-    dt, prof, stats, n_local = run_gpu(v, ages, a.seed, a.steps, a.warmup, device, dist, preheat=a.preheat_days, stride=a.time_every)
-    if world > 1:
+    def max_over_ranks(dt):
+        if world == 1:
+            return dt
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    import numpy as _np
-    total_agents = int(_np.asarray(ages).sum())
+        return float(t.item())
+
+    res = run_gpu(v, ages, a.seed, a.steps, a.warmup, device, dist, preheat=a.preheat_days, stride=stride)
+    res['dt'] = max_over_ranks(res['dt'])
+    total_agents = int(np.asarray(ages).sum())
     n_agents = total_agents // world   # agents one k_scan launch streams on this rank
-    value = total_agents * a.steps / dt
+    value = total_agents * a.steps / res['dt']
 
     large_sharded = None
     if world > 1 and not a.no_large and not a.agents:
-        # BASELINE configs[3] shape on the same ranks: 50 M agents per GPU (4 x 10^8 on 8), sharded
+        # BASELINE configs[3] shape on the same ranks: 50 M agents per GPU (4 x 10^8 on 8), sharded, full scenario
         vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.large_agents * world)
-        dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, dist,
-                                         preheat=min(a.preheat_days, 120), stride=a.time_every, preheat_runs=1)
-        t = torch.tensor([dtl], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dtl = float(t.item())
-        tot_l = int(_np.asarray(agesl).sum())
+        rl = run_gpu(vl, agesl, a.seed, 365, 0, device, dist, preheat=60, stride=16, preheat_runs=1)
+        rl['dt'] = max_over_ranks(rl['dt'])
+        tot_l = int(np.asarray(agesl).sum())
         large_sharded = {
-            'workload': 'synthetic %d agents (%d per GPU, BASELINE configs[3] shape), default scenario scaled, %d days' % (
-                tot_l, tot_l // world, a.steps),
-            'value': round(tot_l * a.steps / dtl, 1), 'unit': 'agent-days/s', 'ms_per_step': round(dtl * 1000 / a.steps, 6),
-            'roofline': roofline_obj(tot_l // world, a.steps, profl, statsl, a.time_every, dtl * 1000 / a.steps),
-            'final_all_infected': statsl['final_all_infected'],
+            'workload': 'synthetic %d agents (%d per GPU, BASELINE configs[3] shape), default scenario scaled, 365 days' % (tot_l, tot_l // world),
+            'value': round(tot_l * 365 / rl['dt'], 1), 'unit': 'agent-days/s', 'ms_per_step': round(rl['dt'] * 1000 / 365, 6),
+            'roofline': roofline_obj(tot_l // world, rl, 365, 16), 'final_all_infected': rl['stats']['final_all_infected'],
         }
+    ens_dist = None
+    if world > 1 and not a.no_ensemble and not a.agents:
+        try:
+            ens_dist = ensemble_line(min(a.ensemble_seeds, 32), 365, device, dist)
+        except Exception as e:   # noqa: BLE001 -- reported in the line itself
+            ens_dist = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
-    out = None
     if rank == 0:
         out = {
             'metric': 'agent-days/sec', 'value': round(value, 1), 'unit': 'agent-days/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(dt * 1000 / a.steps, 6), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(res['dt'] * 1000 / a.steps, 6), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
             'config': {'workload': workload, 'agents_total': total_agents,
                        'parallelism': 'single GPU' if world == 1 else 'agents sharded x%d, one 8 KB RCCL all-reduce of infection pressure per day' % world,
-                       'final_all_infected': stats['final_all_infected']},
-            'roofline': roofline_obj(n_agents, a.steps, prof, stats, a.time_every, dt * 1000 / a.steps),
+                       'final_all_infected': res['stats']['final_all_infected'], 'peak_infected_in_window': res['stats']['peak_infected']},
+            'roofline': roofline_obj(n_agents, res, a.steps, stride, traffic_key),
         }
-        traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(traffic_file):
-            try:
-                tj = json.load(open(traffic_file))
-                key = 'hus' if not a.agents else str(a.agents)
-                if key in tj:
-                    out['roofline']['traffic'] = tj[key]
-            except Exception:
-                pass
-        def extra(key, fn):
+        if world > 1:
+            out['rccl_world'] = res['rccl_world']   # ncclCommCount of the communicator the day stream's all-reduce runs on
+            out['config']['rccl_world'] = res['rccl_world']
+
+        def extra(store, key, fn):
             # the additional workloads must not take the headline line down with them
             try:
-                out[key] = fn()
+                store[key] = fn()
             except Exception as e:   # noqa: BLE001 -- reported in the line itself
-                out[key] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+                store[key] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
-        def sized_line(n_agents_cfg, label, preheat, preheat_runs):
-            vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), n_agents_cfg)
-            dtl, profl, statsl, nl = run_gpu(vl, agesl, a.seed, a.steps, a.warmup, device, preheat=preheat,
-                                             stride=a.time_every, preheat_runs=preheat_runs)
-            line = {
-                'workload': 'synthetic %d agents (%s), default scenario scaled, %d days' % (nl, label, a.steps),
-                'value': round(nl * a.steps / dtl, 1), 'unit': 'agent-days/s',
-                'ms_per_step': round(dtl * 1000 / a.steps, 6),
-                'roofline': roofline_obj(nl, a.steps, profl, statsl, a.time_every, dtl * 1000 / a.steps),
-                'final_all_infected': statsl['final_all_infected'],
-            }
-            try:   # PMC traffic of the same workload (profiles/traffic.json, collected in separate --pmc passes)
-                line['roofline']['traffic'] = json.load(open(traffic_file)).get(str(n_agents_cfg))
-            except Exception:
-                pass
-            return line
+        def full_line(n_cfg, label):
+            if n_cfg:
+                vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), n_cfg)
+                key = str(n_cfg)
+            else:
+                vl, agesl, key = copy.deepcopy(VARIABLE_DEFAULTS), datasets.get_population_for_area(), 'hus'
+            r = run_gpu(vl, agesl, a.seed, 365, 0, device, preheat=60 if n_cfg else 365, stride=16, preheat_runs=1 if n_cfg else 2)
+            nl = r['n_local']
+            return {'workload': '%s: %d agents, default scenario%s, all 365 days' % (label, nl, ' scaled' if n_cfg else ''),
+                    'value': round(nl * 365 / r['dt'], 1), 'unit': 'agent-days/s', 'ms_per_step': round(r['dt'] * 1000 / 365, 6),
+                    'roofline': roofline_obj(nl, r, 365, 16, key), 'final_all_infected': r['stats']['final_all_infected'],
+                    'peak_infected': r['stats']['peak_infected']}
 
-        if not a.no_large and world == 1 and not a.agents:
-            extra('large', lambda: sized_line(a.large_agents, 'BASELINE configs[2]', min(a.preheat_days, 120), 2))
-            if a.xlarge_agents:
-                # SURVEY 8d's second point: a hot array (0.8 GB) that no cache level holds
-                extra('xlarge', lambda: sized_line(a.xlarge_agents, 'SURVEY 8d: HBM-resident regime', min(a.preheat_days, 30), 1))
+        if world == 1 and not a.agents and not a.no_sizes:
+            fs = out['full_scenario'] = {}
+            extra(fs, 'hus', lambda: full_line(0, 'HUS (BASELINE configs[1])'))
+            labels = {50_000_000: 'synthetic 5e7 (BASELINE configs[2])', 100_000_000: "synthetic 1e8 (BASELINE metric's 100 M agents)",
+                      200_000_000: 'synthetic 2e8 (SURVEY 8d: HBM-resident regime)'}
+            for n_cfg in [int(x) for x in a.sizes.split(',') if x]:
+                extra(fs, str(n_cfg), lambda n_cfg=n_cfg: full_line(n_cfg, labels.get(n_cfg, 'synthetic')))
         if large_sharded is not None:
             out['large'] = large_sharded
+        if ens_dist is not None:
+            out['ensemble'] = ens_dist
         if not a.no_ensemble and world == 1 and not a.agents:
-            extra('ensemble', lambda: ensemble_line(a.ensemble_seeds, a.steps, device))
+            extra(out, 'ensemble', lambda: ensemble_line(a.ensemble_seeds, 365, device))
         if not a.no_cpu and world == 1:   # the CPU baseline is an N=1 figure
             hus = datasets.get_population_for_area()
-            out['cpu_baseline'] = cpu_baseline(copy.deepcopy(VARIABLE_DEFAULTS), hus, a.seed, a.cpu_days)
+            out['cpu_baseline'] = cpu_baseline(copy.deepcopy(VARIABLE_DEFAULTS), hus, a.seed, a.steps, a.warmup)
             out['cpu_baseline']['cores_available'] = os.cpu_count()
             try:
                 with open('/proc/cpuinfo') as f:
@@ -410,12 +532,12 @@ def main():
             except Exception:
                 pass
             if cpu_all is not None:
-                res = cpu_all.run()
-                if res is not None:
-                    out['cpu_baseline']['all_cores'] = res
+                r_all = cpu_all.run()
+                if r_all is not None:
+                    out['cpu_baseline']['all_cores'] = r_all
         out['timing'] = {
-            'timed_region_s': round(dt, 6), 'process_wall_s': round(time.perf_counter() - t_process, 2),
-            'note': 'the process also builds contexts, runs untimed preheat simulations, the extra 50 M / ensemble '
+            'timed_region_s': round(res['dt'], 6), 'process_wall_s': round(time.perf_counter() - t_process, 2),
+            'note': 'the process also builds contexts, runs untimed preheat simulations, the full_scenario / ensemble '
                     'configurations and the CPU baselines; value = agents x steps / timed_region_s'}
         print(json.dumps(out), flush=True)
     if world > 1:

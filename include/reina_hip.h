@@ -34,6 +34,8 @@ extern "C" {
 #define REINA_MAX_SCAN_WAVES 8192
 #define REINA_MAX_SHARDS 16     /* ranks an agent population can be sharded over */
 #define REINA_MAX_RANGES 32     /* distinct contact age ranges (reference: 15) */
+#define REINA_MAX_DAYS 4096     /* reina_day_t.day < 4096: winner-selection keys carry the day in 12 bits and are never
+                                   cleared (the reference's default scenario runs 565 days, variables.py:233) */
 #define REINA_PRESSURE_WORDS (REINA_MAX_SHARDS * REINA_MAX_RANGES * REINA_MAX_VARIANTS)
 #define REINA_MIRROR_CELLS (REINA_MAX_RANGES * REINA_MAX_VARIANTS)
 /* sharded populations: the pressure words of contact range REINA_MAX_RANGES - 1 (never a real range: a
@@ -56,7 +58,7 @@ extern "C" {
 #define REINA_PROBLEM_QUEUE_OVERFLOW 102
 #define REINA_PROBLEM_HOSPITAL_OVERFLOW 103
 #define REINA_PROBLEM_DAYS_OVERFLOW 104
-#define REINA_PROBLEM_SYNC_TIMEOUT 105   /* a workgroup waited > 20 ms for the day's opening bookkeeping */
+#define REINA_PROBLEM_SYNC_TIMEOUT 105   /* a workgroup gave up waiting (2^22 polls, seconds) for the day's opening bookkeeping */
 
 /* per-age counter arrays, Population stats main.pyx:1335-1341 */
 enum {
@@ -87,6 +89,8 @@ enum {
     REINA_L_TRACE_DONE,                                 /* level-0 tracing workgroups finished today (folded level 1) */
     REINA_L_CAND_OVF,                                   /* candidate records that did not fit their slice's region today */
     REINA_L_HOSP_PEAK,                                  /* busiest multi-range day so far: its bed / ICU event count (0: every day fit one pass) */
+    REINA_L_OPEN_TICKET,                                /* arrival tickets of the day-opening launch: 0 opens the day, 1 places the weekly
+                                                           imports, 2.. work off the test queue; reset by the launch's last arrival */
     REINA_L_VACC_CURSOR = 16,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_NR = 32
 };
@@ -304,10 +308,21 @@ int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_d
 /* replaces Context.generate_state's reads (main.pyx:1813-1857): copies the counter block to host
  * (synchronises `stream`) */
 int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);
-/* timing hooks for bench.py: HIP events recorded around the scan kernel on `stream`.
- * enable: 0 off, 1 every day, k > 1 the days with day % k == 0 (a timestamped dispatch costs a
- * few microseconds of stream time, which matters when a whole day takes 80) */
+/* timing hooks for bench.py: HIP events on the launch stream around the day's kernels (start / stop
+ * timestamps of the kernel's own dispatch packet).
+ * enable: 0 off; 1 every kernel of every day; k > 1: one KIND of kernel per profiled day, the kinds taking
+ * turns -- k_scan on days with day % k == 0, k_open (+ the occasional kernels: level-1 tracing, vaccination,
+ * cross-shard realisation) at k/4, k_hosp_contacts at k/2, k_install at 3k/4 -- so that the cost of
+ * timestamped dispatches (a few microseconds each, which matters when a whole day takes 45) stays small.
+ * reina_profile_read_kernels: summed milliseconds and launch counts per kind since the last read, arrays of
+ * REINA_PK_NR; synchronises the device.  reina_profile_read: the k_scan pair of those numbers and the sum
+ * over all kinds. */
+enum {
+    REINA_PK_OPEN = 0, REINA_PK_TRACE1, REINA_PK_VACCINATE, REINA_PK_SCAN, REINA_PK_HOSP_CONTACTS, REINA_PK_REMOTE,
+    REINA_PK_INSTALL, REINA_PK_NR
+};
 int reina_profile_enable(reina_engine_t *e, int enable);
+int reina_profile_read_kernels(reina_engine_t *e, double *ms_total, uint64_t *launches);
 int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_launches,
                        double *all_ms_total);
 /* replaces Context.sample(what, age, severity) (main.pyx:2047-2101): n draws of one per-agent

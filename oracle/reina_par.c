@@ -968,6 +968,7 @@ static void run_install(Par *e, const reina_day_t *dp) {
 int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
     (void)stream;
     if (!e->bound) return REINA_E_NOT_BOUND;
+    if (dp->day >= REINA_MAX_DAYS) return REINA_E_INVALID;   /* the 12-bit day tag of rp_order_key, as the engine */
     if (dp->history_row) memcpy(dp->history_row, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
     uint32_t import_base = 0;
     SC(e, REINA_S_DAY) = (int32_t)dp->day + 1;
@@ -1088,6 +1089,11 @@ int par_read_counters(Par *e, int32_t *out, void *stream) {
 }
 int par_profile_enable(Par *e, int en) { (void)e; (void)en; return 0; }
 int par_profile_read(Par *e, double *a, uint64_t *b, double *c) { (void)e; *a = 0; *b = 0; *c = 0; return 0; }
+int par_profile_read_kernels(Par *e, double *ms, uint64_t *n) {
+    (void)e;
+    for (int k = 0; k < REINA_PK_NR; k++) { ms[k] = 0; n[k] = 0; }
+    return 0;
+}
 const char *par_last_error(void) { return ""; }
 
 /* ---- primitive test hooks (checked against scipy / known answers in tests/test_prims.py) ---- */

@@ -59,31 +59,88 @@ static int grid_for(uint32_t n_items, int threads, int max_blocks) {
     return (int)blocks;
 }
 
-static size_t take_event(reina_engine *e) {
-    if (e->ev_used == e->ev_pool.size()) {
+// HIP-event timing of the day's kernels (reina_profile_enable): start/stop timestamps ride on the kernel's
+// own dispatch packet (hipExtLaunchKernelGGL), no extra stream commands.  On a profiled day ONE kind of kernel
+// is timed (the kinds take turns), so the cost of timestamped dispatches is spread thinly over the run.
+static bool take_event_pair(reina_engine *e, size_t *a, size_t *b) {
+    while (e->ev_used + 2 > e->ev_pool.size()) {
+        if (e->ev_pool.size() >= reina_engine::MAX_EVENTS) return false;   // pool exhausted: this launch goes untimed
         hipEvent_t ev = nullptr;
-        (void)hipEventCreate(&ev);   // (a failed creation surfaces as an invalid-handle error at the launch)
+        if (hipEventCreate(&ev) != hipSuccess || !ev) return false;
         e->ev_pool.push_back(ev);
     }
-    return e->ev_used++;
+    *a = e->ev_used++;
+    *b = e->ev_used++;
+    return true;
 }
 
+// which kind of kernel carries timestamps on `day` (-1: none)
+static int profiled_kind(const reina_engine *e, uint32_t day) {
+    if (!e->profile) return -1;
+    const uint32_t stride = e->profile_stride;
+    if (stride <= 1) return REINA_PK_NR;        // every kernel, every day
+    const uint32_t ph = day % stride;
+    // the four kernels of every day at evenly spaced phases; the occasional ones ride with k_open's phase
+    if (ph == 0) return REINA_PK_SCAN;
+    if (ph == stride / 4) return REINA_PK_OPEN;
+    if (ph == stride / 2) return REINA_PK_HOSP_CONTACTS;
+    if (ph == stride / 2 + stride / 4) return REINA_PK_INSTALL;
+    return -1;
+}
+static bool kind_timed(int today, int kind) {
+    if (today < 0) return false;
+    if (today == REINA_PK_NR || today == kind) return true;
+    // kernels that do not run every day are timed on k_open's days
+    return today == REINA_PK_OPEN && (kind == REINA_PK_TRACE1 || kind == REINA_PK_VACCINATE || kind == REINA_PK_REMOTE);
+}
+
+#define LAUNCH_TIMED(e, today, kind, kernel, grid, block, lds, stream, ...)                                              \
+    do {                                                                                                                 \
+        size_t ev_a_, ev_b_;                                                                                             \
+        if (kind_timed(today, kind) && take_event_pair(e, &ev_a_, &ev_b_)) {                                             \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, (e)->ev_pool[ev_a_], (e)->ev_pool[ev_b_], 0, __VA_ARGS__); \
+            (e)->kpairs[kind].emplace_back(ev_a_, ev_b_);                                                                \
+        } else {                                                                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                           \
+        }                                                                                                                \
+    } while (0)
+
 static void resolve_profile(reina_engine *e) {
-    for (auto &p : e->scan_pairs) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, e->ev_pool[p.first], e->ev_pool[p.second]) == hipSuccess) {
-            e->scan_ms += ms;
-            e->scan_launches++;
+    for (int k = 0; k < REINA_PK_NR; k++) {
+        for (auto &p : e->kpairs[k]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e->ev_pool[p.first], e->ev_pool[p.second]) == hipSuccess) {
+                e->k_ms[k] += ms;
+                e->k_launches[k]++;
+            }
         }
+        e->kpairs[k].clear();
     }
-    for (auto &p : e->day_pairs) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, e->ev_pool[p.first], e->ev_pool[p.second]) == hipSuccess) e->all_ms += ms;
-    }
-    e->scan_pairs.clear();
-    e->day_pairs.clear();
     e->ev_used = 0;
 }
+
+// frees what reina_create / reina_group_create had acquired when a later step fails
+static void free_engine(reina_engine *e) {
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (size_t k = 0; k < e->stage.size(); k++) {
+        (void)hipEventSynchronize(e->stage_ev[k]);
+        (void)hipEventDestroy(e->stage_ev[k]);
+        (void)hipHostFree(e->stage[k]);
+    }
+    if (e->d_params) (void)hipFree(e->d_params);
+    if (e->d_tables) (void)hipFree(e->d_tables);
+    if (e->d_ref) (void)hipFree(e->d_ref);
+    delete e;
+}
+#define HIP_CHECK_OR(x, cleanup)                                                             \
+    do {                                                                                     \
+        hipError_t _e = (x);                                                                 \
+        if (_e != hipSuccess) {                                                              \
+            g_last_error = std::string(#x) + ": " + hipGetErrorString(_e);                   \
+            cleanup;                                                                         \
+            return REINA_E_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
 
 extern "C" {
 
@@ -117,6 +174,11 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         g_last_error = "no HIP device";
         return REINA_E_HIP;
     }
+    for (uint32_t a = 0; a < cfg->nr_ages; a++)
+        if (cfg->age_start[a] < 0 || cfg->age_start[a] > cfg->age_start[a + 1] || (uint32_t)cfg->age_start[a + 1] > cfg->n_agents) {
+            g_last_error = "age_start must be non-decreasing and end at n_agents";
+            return REINA_E_INVALID;
+        }
     reina_engine *e = new reina_engine();
     e->cfg = *cfg;
     {   // compute units of the current device: grids of one-workgroup-per-CU kernels are sized to it
@@ -172,16 +234,16 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     }
     e->h_params.max_queue = cfg->max_queue;
     e->h_params.max_hosp_events = cfg->max_hosp_events > REINA_MAX_HOSP_EVENTS ? cfg->max_hosp_events : REINA_MAX_HOSP_EVENTS;
-    HIP_CHECK(hipMalloc(&e->d_params, sizeof(DevParams)));
-    HIP_CHECK(hipMalloc(&e->d_tables, sizeof(Tables)));
-    HIP_CHECK(hipMalloc(&e->d_ref, sizeof(MemberRef)));
-    HIP_CHECK(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice));
+    HIP_CHECK_OR(hipMalloc(&e->d_params, sizeof(DevParams)), free_engine(e));
+    HIP_CHECK_OR(hipMalloc(&e->d_tables, sizeof(Tables)), free_engine(e));
+    HIP_CHECK_OR(hipMalloc(&e->d_ref, sizeof(MemberRef)), free_engine(e));
+    HIP_CHECK_OR(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice), free_engine(e));
+    HIP_CHECK_OR(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice), free_engine(e));
     {
         size_t lds = con_shared_bytes(REINA_MAX_AGES, REINA_MAX_SHARDS);
         if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_contacts),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_contacts),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), free_engine(e));
     }
     *out = e;
     return REINA_OK;
@@ -189,17 +251,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
 
 int reina_destroy(reina_engine_t *e) {
     if (!e) return REINA_E_INVALID;
-    // teardown: nothing useful can be done about a failing free
-    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-    for (size_t k = 0; k < e->stage.size(); k++) {
-        (void)hipEventSynchronize(e->stage_ev[k]);
-        (void)hipEventDestroy(e->stage_ev[k]);
-        (void)hipHostFree(e->stage[k]);
-    }
-    (void)hipFree(e->d_params);
-    (void)hipFree(e->d_tables);
-    (void)hipFree(e->d_ref);
-    delete e;
+    free_engine(e);   // teardown: nothing useful can be done about a failing free
     return REINA_OK;
 }
 
@@ -242,6 +294,15 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     if (!e || !t) return REINA_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t A = e->cfg.nr_ages;
+    if (t->n_ranges > REINA_MAX_RANGES) {
+        g_last_error = "more than REINA_MAX_RANGES contact ranges";
+        return REINA_E_INVALID;
+    }
+    for (uint32_t a = 0; a < A; a++)
+        if (t->count[a] < 0 || t->count[a] > REINA_MAX_ENTRIES) {
+            g_last_error = "contact entries per age must be in [0, REINA_MAX_ENTRIES]";
+            return REINA_E_INVALID;
+        }
     if (e->cfg.n_shards > 1 && t->n_ranges >= REINA_MAX_RANGES) {
         g_last_error = "a sharded engine takes at most REINA_MAX_RANGES - 1 contact ranges (the last range's pressure words carry free capacity)";
         return REINA_E_INVALID;
@@ -341,41 +402,44 @@ static uint32_t scan_blocks_for(uint32_t n_agents, uint32_t K, uint32_t n_cus) {
 static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp,
                             uint32_t hist_slot, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
+    if (dp.day >= REINA_MAX_DAYS) {
+        // claim / mirror keys carry the day in 12 bits (rp_order_key) and claim[] is never cleared: from day
+        // 4096 on, stale claims would beat today's
+        g_last_error = "day >= REINA_MAX_DAYS (4096): the winner-selection keys carry the day in 12 bits";
+        return REINA_E_INVALID;
+    }
+    if (dp.n_import_batches > REINA_MAX_IMPORT_BATCHES || dp.n_vaccinations > REINA_MAX_VACCINATIONS) {
+        g_last_error = "n_import_batches / n_vaccinations out of range";
+        return REINA_E_INVALID;
+    }
+    const int today = profiled_kind(e, dp.day);
     if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
     uint32_t n_pre = 0, n_post = 0;
     for (uint32_t b = 0; b < dp.n_import_batches; b++)
         (dp.import_batches[b].pre_init ? n_pre : n_post) += dp.import_batches[b].count;
     const int weekly_own = n_pre == 0 && n_post > 0;   // (intervention imports share the claim keys: same workgroup then)
     if (!e->testing_ever) {
-        hipLaunchKernelGGL(k_open<0>, dim3(2, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
+        LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open<0>, dim3(2, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
     } else {
         // (groups: the members share the chip, so each gets proportionally fewer workgroups per phase)
         int tg = grid_for(N / 64 + 1, PRO_THREADS, 64);
         if (K > 1 && tg > (int)(e->n_cus / K)) tg = e->n_cus / K > 0 ? (int)(e->n_cus / K) : 1;
         const int g = 2 + tg;
         if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT && N <= 8000000u) {
-            hipLaunchKernelGGL(k_open<3>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces, both levels
+            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open<3>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces, both levels
         } else if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            hipLaunchKernelGGL(k_open<2>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces level 0
-            hipLaunchKernelGGL(k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
+            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open<2>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces level 0
+            LAUNCH_TIMED(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
         } else {
-            hipLaunchKernelGGL(k_open<1>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
+            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open<1>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
         }
     }
-    if (dp.n_vaccinations) hipLaunchKernelGGL(k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
+    if (dp.n_vaccinations) LAUNCH_TIMED(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
     // scan geometry: tiles of 512 agents, as many waves as tiles (small populations) up to 8192
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
     const uint32_t scan_blocks = scan_blocks_for(N, K, e->n_cus);
     const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
-    if (e->profile && K == 1 && dp.day % e->profile_stride == 0) {
-        // start/stop timestamps ride on the kernel's own dispatch packet: no extra stream commands
-        const size_t ev_s0 = take_event(e), ev_s1 = take_event(e);
-        hipExtLaunchKernelGGL(k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, e->ev_pool[ev_s0], e->ev_pool[ev_s1], 0,
-                              refs, dp);
-        e->scan_pairs.emplace_back(ev_s0, ev_s1);
-    } else {
-        hipLaunchKernelGGL(k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, refs, dp);
-    }
+    LAUNCH_TIMED(e, today, REINA_PK_SCAN, k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, refs, dp);
     {   // bed / ICU events (workgroup 0, latency-bound) beside the contact sampling (workgroups 1..)
         const uint32_t con_blocks = con_blocks_for(scan_waves, e->n_cus, K);
         size_t lds = con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards);
@@ -384,8 +448,8 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         uint32_t group_slices = scan_waves / (con_blocks * CON_WAVES);
         if (group_slices < 4) group_slices = 1;   // (measured: grouping 2 dense slices of a 50 M population costs more than it fills)
         if (group_slices > 8) group_slices = 8;
-        hipLaunchKernelGGL(k_hosp_contacts, dim3(con_blocks + 1, K), dim3(CON_THREADS), lds, s, refs, dp, scan_waves, scan_tiles,
-                           e->uniform_meta, group_slices);
+        LAUNCH_TIMED(e, today, REINA_PK_HOSP_CONTACTS, k_hosp_contacts, dim3(con_blocks + 1, K), dim3(CON_THREADS), lds, s, refs, dp,
+                     scan_waves, scan_tiles, e->uniform_meta, group_slices);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
@@ -393,8 +457,9 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
 
 static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
+    const int today = profiled_kind(e, dp.day);
     if (e->cfg.n_shards > 1)
-        hipLaunchKernelGGL(k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
+        LAUNCH_TIMED(e, today, REINA_PK_REMOTE, k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
         const uint32_t scan_blocks = scan_blocks_for(N, K, e->n_cus);
@@ -402,7 +467,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         // (groups: 512 workgroups for all members together -- measured on 8 / 32 / 128 HUS-sized members against
         // 256, 1024, 2048 and 4096: every workgroup pays its prologue and its histogram flush)
         if (K > 1 && ig > (int)(512 / K)) ig = (int)(512 / K) >= 2 ? ((int)(512 / K) & ~1) : 2;
-        hipLaunchKernelGGL(k_install, dim3(ig, K), dim3(256), 0, s, refs, dp, scan_blocks * SCAN_WAVES, scan_tiles);
+        LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_install, dim3(ig, K), dim3(256), 0, s, refs, dp, scan_blocks * SCAN_WAVES, scan_tiles);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
@@ -487,8 +552,9 @@ int reina_group_create(reina_engine_t **engines, uint32_t n, reina_group_t **out
         g->h_refs[k].B = engines[k]->buf;
         g->h_refs[k].history_base = nullptr;
     }
-    HIP_CHECK(hipMalloc(&g->d_refs, sizeof(MemberRef) * n));
-    HIP_CHECK(hipMemcpy(g->d_refs, g->h_refs.data(), sizeof(MemberRef) * n, hipMemcpyHostToDevice));   // (table broadcasts may precede the first run)
+    HIP_CHECK_OR(hipMalloc(&g->d_refs, sizeof(MemberRef) * n), delete g);
+    HIP_CHECK_OR(hipMemcpy(g->d_refs, g->h_refs.data(), sizeof(MemberRef) * n, hipMemcpyHostToDevice),   // (table broadcasts may precede the first run)
+                 { (void)hipFree(g->d_refs); delete g; });
     *out = g;
     return REINA_OK;
 }
@@ -580,8 +646,8 @@ int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream) {
 int reina_profile_enable(reina_engine_t *e, int enable) {
     if (!e) return REINA_E_INVALID;
     e->profile = enable != 0;
-    e->profile_stride = enable > 1 ? (uint32_t)enable : 1u;
-    // create the timing events up front: hipEventCreate inside a timed region costs microseconds each
+    e->profile_stride = enable > 1 ? (uint32_t)(enable < 4 ? 4 : enable) : 1u;   // (four kinds take turns: stride >= 4)
+    // create timing events up front: hipEventCreate inside a timed region costs microseconds each
     while (e->profile && e->ev_pool.size() < 1024) {
         hipEvent_t ev;
         HIP_CHECK(hipEventCreate(&ev));
@@ -590,16 +656,30 @@ int reina_profile_enable(reina_engine_t *e, int enable) {
     return REINA_OK;
 }
 
-int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_launches, double *all_ms_total) {
+int reina_profile_read_kernels(reina_engine_t *e, double *ms_total, uint64_t *launches) {
     if (!e) return REINA_E_INVALID;
     HIP_CHECK(hipDeviceSynchronize());
     resolve_profile(e);
-    if (scan_ms_total) *scan_ms_total = e->scan_ms;
-    if (scan_launches) *scan_launches = e->scan_launches;
-    if (all_ms_total) *all_ms_total = e->all_ms;
-    e->scan_ms = 0;
-    e->all_ms = 0;
-    e->scan_launches = 0;
+    for (int k = 0; k < REINA_PK_NR; k++) {
+        if (ms_total) ms_total[k] = e->k_ms[k];
+        if (launches) launches[k] = e->k_launches[k];
+        e->k_ms[k] = 0;
+        e->k_launches[k] = 0;
+    }
+    return REINA_OK;
+}
+
+int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_launches, double *all_ms_total) {
+    double ms[REINA_PK_NR];
+    uint64_t n[REINA_PK_NR];
+    const int rc = reina_profile_read_kernels(e, ms, n);
+    if (rc) return rc;
+    if (scan_ms_total) *scan_ms_total = ms[REINA_PK_SCAN];
+    if (scan_launches) *scan_launches = n[REINA_PK_SCAN];
+    if (all_ms_total) {   // every timed launch of every kind
+        *all_ms_total = 0;
+        for (int k = 0; k < REINA_PK_NR; k++) *all_ms_total += ms[k];
+    }
     return REINA_OK;
 }
 

@@ -43,9 +43,12 @@ S_NR = 32
 COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 32
 L_HOSP_PEAK = 12   # control word: event count of the busiest day that needed several priority ranges
+MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
+PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_scan', 'k_hosp_contacts', 'k_remote', 'k_install')
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
                  'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
+                 'profile_read_kernels',
                  'group_create', 'group_destroy', 'group_upload_contact_tables', 'group_run_days',
                  'build_contact_tables', 'last_error', 'abi_version')
 
@@ -153,6 +156,7 @@ def bind_abi(lib, prefix):
     f['profile_enable'].argtypes = [vp, ctypes.c_int]
     f['profile_read'].argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                                   ctypes.POINTER(ctypes.c_double)]
+    f['profile_read_kernels'].argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     f['last_error'].restype = ctypes.c_char_p
     f['last_error'].argtypes = []
     f['abi_version'].argtypes = []
@@ -351,6 +355,13 @@ class Engine:
         a, b, c = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_double()
         self._check(self.f['profile_read'](self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), 'profile_read')
         return dict(scan_ms_total=a.value, scan_launches=b.value, all_ms_total=c.value)
+
+    def profile_read_kernels(self):
+        """{kernel: (summed ms, timed launches)} since the last read, HIP events on the launch stream"""
+        n = len(PROFILE_KINDS)
+        ms, cnt = (ctypes.c_double * n)(), (ctypes.c_uint64 * n)()
+        self._check(self.f['profile_read_kernels'](self._h, ms, cnt), 'profile_read_kernels')
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(PROFILE_KINDS)}
 
 
 class EngineGroup:

@@ -70,7 +70,7 @@ def _same_day_descriptors(p, q):
     return True
 
 
-def run_sweep(variables_list, seeds, days, age_counts=None, device='cuda:0', engine_factory=None):
+def run_sweep(variables_list, seeds, days, age_counts=None, device='cuda:0', engine_factory=None, ipc='auto'):
     """BASELINE config 5's "intervention sweep": member m runs scenario variables_list[m] with seed
     seeds[m], all as ONE engine group.  The scenarios must agree in everything that goes into the day
     descriptors (dates, testing modes, imports, vaccination, capacities) and in the dates of their
@@ -79,10 +79,10 @@ def run_sweep(variables_list, seeds, days, age_counts=None, device='cuda:0', eng
     assert len(variables_list) == len(seeds)
     plans, ctxs = [], []
     for v, sd in zip(variables_list, seeds):
-        planner = simulation.make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory)
+        planner = simulation.make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory, ipc=ipc)
         plans.append(planner.make_plan(days))
         del planner
-        ctxs.append(simulation.make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory))
+        ctxs.append(simulation.make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory, ipc=ipc))
     for k, p in enumerate(plans[1:], 1):
         if not _same_day_descriptors(plans[0], p):
             raise ValueError('scenario %d differs from scenario 0 in more than the values of its mobility / mask '
@@ -111,22 +111,23 @@ def run_ensemble_distributed(variables, seeds, days, group=None, concurrent=64, 
 
 
 def run_ensemble(variables, seeds, days, age_counts=None, device='cuda:0', threads=8, concurrent=None,
-                 interventions=None, batched=True, engine_factory=None):
+                 interventions=None, batched=True, engine_factory=None, ipc='auto'):
     """Run one simulation per seed for `days` days. Returns history[len(seeds), days, COUNTER_WORDS]
     (row d = counters before day d, as Context.run). `concurrent` bounds how many members hold HBM
-    state at once (default: all)."""
+    state at once (default: all).  `ipc`: the initial population condition of every member; 'auto' = the
+    one simulate_individuals applies for these variables (calc/simulation.py:152), None = none."""
     import torch
     seeds = list(seeds)
     concurrent = len(seeds) if concurrent is None else max(1, int(concurrent))
     if batched:
         planner = simulation.make_context(variables, age_counts=age_counts, seed=seeds[0], device=device,
-                                          interventions=interventions, engine_factory=engine_factory)
+                                          interventions=interventions, engine_factory=engine_factory, ipc=ipc)
         plan = planner.make_plan(days)
         del planner
         outs = []
         for start in range(0, len(seeds), concurrent):
             ctxs = [simulation.make_context(variables, age_counts=age_counts, seed=sd, device=device,
-                                            interventions=interventions, engine_factory=engine_factory)
+                                            interventions=interventions, engine_factory=engine_factory, ipc=ipc)
                     for sd in seeds[start:start + concurrent]]
             outs.append(run_group_plan(ctxs, plan))
             del ctxs
@@ -136,7 +137,7 @@ def run_ensemble(variables, seeds, days, age_counts=None, device='cuda:0', threa
     lock = threading.Lock()
     # the day descriptors do not depend on the seed: plan the scenario once, replay it per member
     planner = simulation.make_context(variables, age_counts=age_counts, seed=seeds[0], device=device,
-                                      interventions=interventions)
+                                      interventions=interventions, ipc=ipc)
     plan = planner.make_plan(days)
     del planner
 
@@ -146,7 +147,7 @@ def run_ensemble(variables, seeds, days, age_counts=None, device='cuda:0', threa
         with torch.cuda.stream(stream):
             with lock:  # context construction touches shared Python state (allocator, caches)
                 ctx = simulation.make_context(variables, age_counts=age_counts, seed=seeds[k], device=device,
-                                              interventions=interventions)
+                                              interventions=interventions, ipc=ipc)
             hist = ctx.run_plan(plan)
             stream.synchronize()
         out[k] = hist

@@ -14,6 +14,8 @@ Differences a caller can observe (DESIGN.md "Parity tiers"):
     stream, so a given seed yields a different but statistically equivalent trajectory;
   * `iterate()` only enqueues GPU work; problems surface at the next `generate_state()` /
     `synchronize()` (the reference raises at the end of `iterate()`, main.pyx:2017-2018).
+    `Context(..., strict=True)` (or `ctx.strict = True`) restores the reference's behaviour: every
+    `iterate()` waits for its day and raises `SimulationFailed` on the day of the problem.
 """
 import ctypes
 from datetime import date, timedelta
@@ -224,12 +226,13 @@ class Context:
     """MI355X-native agent engine with the reference `Context` protocol (main.pyx:1746-2101)."""
 
     def __init__(self, population_params, healthcare_params, disease_params, start_date,
-                 random_seed=4321, device='cuda:0', engine_factory=None, comm=None):
+                 random_seed=4321, device='cuda:0', engine_factory=None, comm=None, strict=False):
         """`comm` (sharding.TorchComm or compatible: .rank, .world, .all_reduce_sum/max) makes this
         Context one shard of a population split over comm.world engine instances; population,
         beds, ICU units and import / vaccination quotas given here are the GLOBAL ones."""
         from .sharding import split_count, split_population
         self.comm = comm
+        self.strict = bool(strict)   # iterate() raises on the day of a problem (main.pyx:2017-2018)
         # testing aid: take the begin / all-reduce / end path even with a single shard
         self.always_collective = bool(comm is not None and getattr(comm, 'always_collective', False))
         self._direct = getattr(comm, 'direct', None) if comm is not None else None
@@ -449,6 +452,8 @@ class Context:
                 by_date.setdefault(iv.date, []).append(iv)
             self._iv_index = (len(self.interventions), by_date)
             self._date0 = date.fromisoformat(self.start_date)
+        if self.day >= _eng.MAX_DAYS:
+            raise SimulationFailed('Day counter overflow: the engine simulates at most %d days' % _eng.MAX_DAYS)
         today = (self._date0 + timedelta(days=self.day)).isoformat()
         for iv in self._iv_index[1].get(today, ()):
             self.apply_intervention(iv)
@@ -518,6 +523,9 @@ class Context:
             self._upload_tables()
         self._step(d)
         self.day += 1
+        if self.strict:
+            # the reference checks `problem` at the end of iterate() (main.pyx:2017-2018): wait for the day
+            self._raise_on_problem(self._read_counters_global())
         if self.n_shards == 1 and not self.always_collective:
             self.engine.prefetch_counters()   # the next generate_state() finds them on the host
 

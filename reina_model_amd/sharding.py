@@ -36,32 +36,66 @@ class DirectRccl:
     event waits plus Python time per day.  The library is the RCCL PyTorch itself loaded
     (torch/lib/librccl.so); the unique id travels through the existing torch.distributed group."""
 
-    def __init__(self, dist, group, rank, world):
+    def __init__(self, dist, group, rank, world, lib_loader=None):
+        """Collective: every rank of `group` must call this together.  No rank raises before ALL ranks
+        have left the last collective of the construction, so a local failure (library not loadable,
+        ncclGetUniqueId error) can never leave the others inside a mismatched collective: the phases are
+        (1) local preparation, failures recorded; (2) the unique id -- or a failure marker -- is broadcast,
+        every rank joins; (3) an all-reduce (MIN) agrees whether EVERY rank is ready; only then
+        (4) ncclCommInitRank, entered by all ranks or by none; (5) a second agreement on its outcome."""
         import ctypes
         import os
         import torch
-        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-        self.lib = ctypes.CDLL(path)
+        self.comm = None
+        self.lib = None
+        err = None
 
         class UniqueId(ctypes.Structure):
             _fields_ = [('internal', ctypes.c_char * 128)]
 
         uid = UniqueId()
-        if rank == 0:
-            rc = self.lib.ncclGetUniqueId(ctypes.byref(uid))
-            if rc != 0:
-                raise RuntimeError('ncclGetUniqueId failed: %d' % rc)
-        box = [bytes(bytearray(uid)) if rank == 0 else None]
-        # (also with a single rank: the one-GPU test box then exercises the call)
+        try:   # (1) nothing here communicates
+            path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+            self.lib = ctypes.CDLL(path) if lib_loader is None else lib_loader()   # (lib_loader: test hook)
+            if rank == 0:
+                rc = self.lib.ncclGetUniqueId(ctypes.byref(uid))
+                if rc != 0:
+                    raise RuntimeError('ncclGetUniqueId failed: %d' % rc)
+        except Exception as e:   # noqa: BLE001 -- reported after the agreement below
+            err = e
+        # (2) also with a single rank: the one-GPU test box then exercises the call
+        box = [(bytes(bytearray(uid)) if err is None else None) if rank == 0 else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if box[0] is None and err is None:
+            err = RuntimeError('rank 0 could not create an RCCL unique id')
+
+        def agree(ok):   # (3) / (5): MIN over the ranks, on the backend's own device
+            dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return int(t.item()) == 1
+
+        if not agree(err is None):
+            raise err if err is not None else RuntimeError('another rank could not prepare its RCCL communicator')
         ctypes.memmove(ctypes.byref(uid), box[0], 128)
-        self.comm = ctypes.c_void_p()
+        comm = ctypes.c_void_p()
         self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
-        rc = self.lib.ncclCommInitRank(ctypes.byref(self.comm), int(world), uid, int(rank))
-        if rc != 0:
-            raise RuntimeError('ncclCommInitRank failed: %d' % rc)
+        rc = self.lib.ncclCommInitRank(ctypes.byref(comm), int(world), uid, int(rank))   # (4)
+        if rc == 0:
+            self.comm = comm
+        if not agree(rc == 0):
+            self.close()
+            raise RuntimeError('ncclCommInitRank failed: %d' % rc if rc != 0 else 'ncclCommInitRank failed on another rank')
         self.fn_ptr = ctypes.cast(self.lib.ncclAllReduce, ctypes.c_void_p).value
         self.comm_ptr = self.comm.value
+
+    def count(self):
+        """ranks RCCL itself reports for this communicator (ncclCommCount)"""
+        import ctypes
+        n = ctypes.c_int(0)
+        self.lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        rc = self.lib.ncclCommCount(self.comm, ctypes.byref(n))
+        return int(n.value) if rc == 0 else -1
 
     def close(self):
         import ctypes
@@ -88,22 +122,16 @@ class TorchComm:
         self.direct = None
         import os
         if self._nccl and os.environ.get('REINA_DIRECT_RCCL', '1') != '0':
+            # DirectRccl's construction is itself collective and ends with an agreement: either every rank
+            # holds a communicator afterwards or every rank has raised, so all take the same route (one rank
+            # on torch.distributed while the others sit in the direct communicator's all-reduce would hang
+            # the day loop)
             try:
                 self.direct = DirectRccl(dist, group, self.rank, self.world)
-            except Exception as e:   # fall back to torch.distributed for the per-day exchange
+            except Exception as e:   # noqa: BLE001 -- all ranks land here together
                 import sys
                 print('reina: direct RCCL communicator unavailable (%s); using torch.distributed' % e, file=sys.stderr)
                 self.direct = None
-            if True:
-                # every rank must take the same route: one rank on torch.distributed while the others sit in
-                # the direct communicator's all-reduce would hang the day loop (also run with a single rank,
-                # so that the one-GPU test box exercises these lines)
-                ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32,
-                                  device=torch.device('cuda', torch.cuda.current_device()))
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-                if int(ok.item()) == 0 and self.direct is not None:
-                    self.direct.close()
-                    self.direct = None
 
     def _as_tensor(self, buf):
         if isinstance(buf, np.ndarray):

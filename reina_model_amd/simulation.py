@@ -53,8 +53,12 @@ def create_disease_params(variables):
 
 
 def make_context(variables, age_counts=None, seed=None, interventions=None, device='cuda:0',
-                 engine_factory=None, comm=None, ipc=None):
-    """Build a Context the way calc/simulation.py:148-180 does."""
+                 engine_factory=None, comm=None, ipc=None, strict=False):
+    """Build a Context the way calc/simulation.py:148-180 does.  `ipc`: an InitialPopulationCondition,
+    a dict of its fields, None (no initial condition), or 'auto' = what simulate_individuals passes,
+    datasets.get_initial_population_condition(variables) (calc/simulation.py:152)."""
+    if isinstance(ipc, str) and ipc == 'auto':
+        ipc = datasets.get_initial_population_condition(variables)
     if age_counts is None:
         age_counts = datasets.get_population_for_area(variables['area_name'])
     age_to_group = datasets.make_age_groups(variables['max_age'])
@@ -69,7 +73,7 @@ def make_context(variables, age_counts=None, seed=None, interventions=None, devi
     hc = dict(hospital_beds=variables['hospital_beds'], icu_units=variables['icu_units'])
     ctx = model.Context(pop_params, hc, create_disease_params(variables), variables['start_date'],
                         random_seed=variables['random_seed'] if seed is None else seed,
-                        device=device, engine_factory=engine_factory, comm=comm)
+                        device=device, engine_factory=engine_factory, comm=comm, strict=strict)
     if interventions is None:
         ivs = get_active_interventions(variables)
     else:
@@ -231,10 +235,12 @@ def simulate_monte_carlo(seed, variables=None, device='cuda:0', engine_factory=N
 
 
 def run_monte_carlo(scenario_name, seeds=range(1000), device='cuda:0', group_size=64, days=None, write_csv=True,
-                    age_counts=None, engine_factory=None, variables=None):
+                    age_counts=None, engine_factory=None, variables=None, ipc='auto'):
     """calc/simulation.py:362-385 with the seeds stepped as engine groups on one GPU instead of a
     process pool: one DataFrame with every run's per-date rows, columns as simulate_individuals
-    plus 'run' and 'scenario'; written to reina_<scenario>.csv like the reference."""
+    plus 'run' and 'scenario'; written to reina_<scenario>.csv like the reference.  Every run starts from
+    the scenario's initial population condition, as the reference's do (run_monte_carlo ->
+    simulate_monte_carlo -> simulate_individuals, calc/simulation.py:152); `ipc` overrides it."""
     import pandas as pd
     from . import ensemble
     from .scenarios import scenario_variables
@@ -244,9 +250,9 @@ def run_monte_carlo(scenario_name, seeds=range(1000), device='cuda:0', group_siz
     dfs = []
     for start in range(0, len(seeds), group_size):
         part = seeds[start:start + group_size]
-        planner = make_context(v, age_counts=age_counts, seed=part[0], device=device, engine_factory=engine_factory)
+        planner = make_context(v, age_counts=age_counts, seed=part[0], device=device, engine_factory=engine_factory, ipc=ipc)
         plan = planner.make_plan(days)
-        members = [make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory)
+        members = [make_context(v, age_counts=age_counts, seed=sd, device=device, engine_factory=engine_factory, ipc=ipc)
                    for sd in part]
         t0 = time.perf_counter()
         hist = ensemble.run_group_plan(members, plan)

@@ -27,6 +27,36 @@ def main():
         dist.init_process_group('gloo')
     from reina_model_amd import datasets, sharding, simulation
     from reina_model_amd import engine as eng
+    if len(sys.argv) > 4 and sys.argv[4] == 'rccl_fail':
+        # DirectRccl's construction is collective: a failure on ONE rank (library not loadable / unique id
+        # not created) must make EVERY rank raise, with the process group still usable afterwards
+        class FakeLib:
+            def __init__(self, uid_rc):
+                self.uid_rc = uid_rc
+
+            def ncclGetUniqueId(self, uid):
+                return self.uid_rc
+
+        def failing_loader():
+            raise OSError('librccl.so: cannot open shared object file (injected)')
+
+        cases = [('loader fails on the last rank', lambda: failing_loader() if rank == world - 1 else FakeLib(0)),
+                 ('loader fails on rank 0', lambda: failing_loader() if rank == 0 else FakeLib(0)),
+                 ('unique id fails on rank 0', lambda: FakeLib(7))]
+        for name, loader in cases:
+            try:
+                sharding.DirectRccl(dist, None, rank, world, lib_loader=loader)
+                raise AssertionError('%s: rank %d did not raise' % (name, rank))
+            except (RuntimeError, OSError):
+                pass
+            t = torch.tensor([rank + 1], dtype=torch.int32)   # the group is intact: same collective on every rank
+            dist.all_reduce(t)
+            assert int(t.item()) == world * (world + 1) // 2, name
+        if rank == 0:
+            print('RCCL_FAIL_OK world=%d' % world, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     from reina_model_amd.variables import VARIABLE_DEFAULTS
     import par_backend
     v = copy.deepcopy(VARIABLE_DEFAULTS)

@@ -43,6 +43,15 @@ def test_gloo_ensemble_is_partitioned_over_the_ranks():
     assert 'ENSEMBLE_OK world=2 members=7' in r.stdout
 
 
+def test_direct_rccl_construction_fails_on_every_rank_together():
+    """a rank that cannot load RCCL or create the unique id must not leave its peers inside a
+    mismatched collective: every rank raises, and the process group keeps working (gloo, world 2, faults
+    injected through DirectRccl's lib_loader hook)."""
+    r = _launch(2, 'gloo', 0, 0, mode='rccl_fail', timeout=180)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'RCCL_FAIL_OK world=2' in r.stdout
+
+
 def test_population_split_is_a_partition():
     import numpy as np
     from reina_model_amd import datasets, sharding

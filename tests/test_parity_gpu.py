@@ -40,20 +40,27 @@ def _assert_state_equal(gpu, cpu):
         qa = np.sort(gpu.engine.alloc.to_host(tg[q])[:cg[l]].view(np.uint32))
         qb = np.sort(np.asarray(tc[q])[:cc[l]].view(np.uint32))
         assert np.array_equal(qa, qb), q
-    # infectee lists: same sets per infector (insertion order is free)
+    # infectee lists: same sets per infector (insertion order is free) -- EVERY chain, walked in lock-step
     fa = gpu.engine.alloc.to_host(tg['first_infectee'])
     na = gpu.engine.alloc.to_host(tg['next_sibling'])
     fb, nb = np.asarray(tc['first_infectee']), np.asarray(tc['next_sibling'])
-    heads = np.nonzero(fb >= 0)[0]
-    assert np.array_equal(heads, np.nonzero(fa >= 0)[0])
-    for h in heads[:2000]:
-        def chain(f, n):
-            out, c = [], f[h]
-            while c >= 0:
-                out.append(c)
-                c = n[c]
-            return sorted(out)
-        assert chain(fa, na) == chain(fb, nb)
+
+    def chain_pairs(f, n):
+        """sorted (infector, infectee) pairs of all lists; a list holds at most 64 entries (main.pyx:128)"""
+        owner = np.nonzero(f >= 0)[0].astype(np.int64)
+        cur = f[owner].astype(np.int64)
+        pairs = []
+        for _ in range(70):
+            if len(cur) == 0:
+                break
+            pairs.append(owner * (1 << 32) + cur)
+            nxt = n[cur].astype(np.int64)
+            keep = nxt >= 0
+            owner, cur = owner[keep], nxt[keep]
+        assert len(cur) == 0, 'an infectee list longer than 64 entries (or a cycle)'
+        return np.sort(np.concatenate(pairs)) if pairs else np.zeros(0, dtype=np.int64)
+
+    assert np.array_equal(chain_pairs(fa, na), chain_pairs(fb, nb)), 'infectee lists'
 
 
 def _run_and_compare(variables, ages, seed, days, interventions=None, chunk=None, ipc=None):
@@ -140,9 +147,9 @@ def test_ragged_population_sizes():
         _run_and_compare(v, datasets.scaled_population(total), 11, 120)
 
 
-@pytest.mark.parametrize('total', [50_000_000, 200_000_000])
+@pytest.mark.parametrize('total', [50_000_000, 100_000_000, 200_000_000])
 def test_conservation_at_scale(total):
-    """BASELINE configs[2] at full size (50 M agents) and SURVEY 8d's HBM-resident point (2 x 10^8, whose
+    """BASELINE configs[2] at full size (50 M agents), the metric's "100 M agents", and SURVEY 8d's HBM-resident point (2 x 10^8, whose
     peak days walk > 50 000 bed / ICU events in priority ranges), 365 days; no oracle run: size-independent
     properties -- every day susceptible+infected+recovered+dead == N, all_infected ==
     infected+recovered+dead, hospitalized == in_ward+in_icu, sum(daily_contacts) == exposed_per_day,
@@ -152,7 +159,7 @@ def test_conservation_at_scale(total):
     ctx = simulation.make_context(v, age_counts=ages, seed=1)
     hist = ctx.run(365)
     peak = int(ctx.engine.alloc.to_host(ctx.engine.tensors['control'])[eng.L_HOSP_PEAK])
-    assert (peak > 3 * 16384) if total > 100_000_000 else (peak == 0), peak
+    assert (peak > 3 * 16384) if total > 100_000_000 else (peak == 0) if total < 100_000_000 else True, peak
     del ctx
     A = eng.MAX_AGES
     N = int(ages.sum())
@@ -520,3 +527,165 @@ def test_large_engine_group_geometry():
     A = eng.MAX_AGES
     i = eng.C_NAMES.index('all_infected')
     assert hist[:, -1, i * A:(i + 1) * A].sum(axis=1).min() > 300
+
+
+def test_config3_at_full_size_eight_shards_of_fifty_million():
+    """BASELINE configs[3] at its stated size on ONE GPU: 4 x 10^8 agents as 8 in-process shards of 5 x 10^7
+    (about 40 GB of HBM), stepped in lock-step with the pressure buffers summed in between.  The first 40
+    days bit for bit against oracle B sharded the same way (per-shard counter blocks; the imports are
+    scaled with the population, so thousands are infected by then), then on through the first wave:
+    conservation over the shards, no problem flag, capacities of the cross-shard candidate region, the
+    mirror table and the bed-event lists hold."""
+    import bench
+    import par_backend
+    from reina_model_amd import sharding
+    v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 400_000_000)
+    G = 8
+    gm, cm = [], []
+    gpu = [simulation.make_context(v, age_counts=ages, seed=6, comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
+    assert min(c.total_people for c in gpu) >= 49_999_900
+    cpu = [simulation.make_context(v, age_counts=ages, seed=6, comm=sharding.InProcessComm(r, G, cm),
+                                   engine_factory=par_backend.par_engine_factory) for r in range(G)]
+    for d in range(40):
+        sharding.step_shards_together(gpu)
+        sharding.step_shards_together(cpu)
+        if d % 10 == 9:
+            for a, b in zip(gpu, cpu):
+                assert np.array_equal(a.engine.read_counters(), b.engine.read_counters()), d
+    for a, b in zip(gpu, cpu):
+        for name in ('hot', 'infector', 'n_infected'):
+            assert np.array_equal(a.engine.alloc.to_host(a.engine.tensors[name]).view(np.uint32),
+                                  np.asarray(b.engine.tensors[name]).view(np.uint32)), name
+    del cpu, cm
+    A = eng.MAX_AGES
+    n = int(np.asarray(ages).sum())
+    tot = None
+    for d in range(40, 130):
+        sharding.step_shards_together(gpu)
+        if d % 30 == 9 or d == 129:
+            c = sharding.reduce_counters(gpu)
+            tot = lambda name: int(c[eng.C_NAMES.index(name) * A:(eng.C_NAMES.index(name) + 1) * A].astype(np.int64).sum())
+            assert tot('susceptible') + tot('infected') + tot('recovered') + tot('dead') == n, d
+            for ctx in gpu:
+                ctx._raise_on_problem(ctx.engine.read_counters())
+    assert tot('all_infected') > 20_000_000
+
+
+def test_config5_per_gpu_batch_of_128_hus_members():
+    """BASELINE config 5's per-GPU batch: 128 seeds x HUS 1 685 983 agents as ONE engine group (one launch
+    per phase for all 128; the day-opening launch is 128 x 66 workgroups whose roles are handed out by
+    arrival tickets), 150 days = through the first wave's peak with saturated ICU -- sampled members ==
+    oracle B run alone with that seed, bit for bit, final state included."""
+    import par_backend
+    from reina_model_amd import ensemble
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ages = datasets.get_population_for_area()
+    days, K = 150, 128
+    planner = simulation.make_context(v, age_counts=ages, seed=0)
+    plan = planner.make_plan(days)
+    members = [simulation.make_context(v, age_counts=ages, seed=4000 + s) for s in range(K)]
+    hist = ensemble.run_group_plan(members, plan)
+    assert hist.shape == (K, days, eng.COUNTER_WORDS)
+    for m in (0, 77, 127):
+        cpu = simulation.make_context(v, age_counts=ages, seed=4000 + m, engine_factory=par_backend.par_engine_factory)
+        assert np.array_equal(hist[m], cpu.run(days)), m
+        _assert_state_equal(members[m], cpu)
+    A = eng.MAX_AGES
+    i = eng.C_NAMES.index('all_infected')
+    assert hist[:, -1, i * A:(i + 1) * A].sum(axis=1).min() > 100_000
+
+
+def test_driver_contract_on_the_hip_engine():
+    """SURVEY 8 f-3 through libreina_hip.so: simulate_individuals' (df, adf) (calc/simulation.py:148-290), the
+    step_callback protocol incl. interruption, sample_model_parameters (:293-347) and run_monte_carlo
+    (:349-385) give the SAME frames on the HIP engine as on the oracle-B engine."""
+    import pandas as pd
+    import par_backend
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=12, icu_units=2, simulation_days=90, random_seed=77)
+    ages = datasets.scaled_population(20000)
+    df_g, adf_g = simulation.simulate_individuals(v, age_counts=ages)
+    df_c, adf_c = simulation.simulate_individuals(v, age_counts=ages, engine_factory=par_backend.par_engine_factory)
+    cols = [c for c in df_g.columns if c != 'us_per_infected']   # (wall-clock column)
+    pd.testing.assert_frame_equal(df_g[cols], df_c[cols])
+    pd.testing.assert_frame_equal(adf_g, adf_c)
+    assert df_g['all_infected'].iloc[-1] > 500 and adf_g.shape == (90, 12 * 9)
+    # the callback path: frames grow by `callback_day_interval` rows, same numbers; returning False interrupts
+    seen = []
+
+    def cb(df):
+        seen.append(int(df['infected'].notna().sum()))
+        return True
+
+    df_s, adf_s = simulation.simulate_individuals(v, age_counts=ages, step_callback=cb, callback_day_interval=7)
+    assert seen == list(range(7, 90, 7)) + [90]
+    pd.testing.assert_frame_equal(df_s[cols], df_c[cols])
+    pd.testing.assert_frame_equal(adf_s, adf_c)
+    calls = []
+    with pytest.raises(simulation.ExecutionInterrupted):
+        simulation.simulate_individuals(v, age_counts=ages, step_callback=lambda df: calls.append(1) or len(calls) < 3,
+                                        callback_day_interval=10)
+    assert len(calls) == 3
+    # sample_model_parameters: host-side samplers of the same library, identical Series
+    for what, age, sev in (('contacts_per_day', 35, None), ('symptom_severity', 70, None), ('incubation_period', 50, None),
+                           ('illness_period', 50, 'MILD'), ('hospitalization_period', 60, 'SEVERE'), ('icu_period', 60, 'CRITICAL'),
+                           ('onset_to_removed_period', 80, 'FATAL'), ('infectiousness', 30, None)):
+        a = simulation.sample_model_parameters(what, age, sev, variables=v)
+        b = simulation.sample_model_parameters(what, age, sev, variables=v, engine_factory=par_backend.par_engine_factory)
+        pd.testing.assert_series_equal(a, b)
+    # run_monte_carlo: 5 seeds in groups of 4 (one full group, one of a single member)
+    mc_g = simulation.run_monte_carlo('default', seeds=range(300, 305), group_size=4, days=60, write_csv=False,
+                                      age_counts=ages, variables=v)
+    mc_c = simulation.run_monte_carlo('default', seeds=range(300, 305), group_size=4, days=60, write_csv=False,
+                                      age_counts=ages, variables=v, engine_factory=par_backend.par_engine_factory)
+    mcols = [c for c in mc_g.columns if c != 'us_per_infected']
+    pd.testing.assert_frame_equal(mc_g[mcols], mc_c[mcols])
+    assert sorted(mc_g['run'].unique()) == list(range(300, 305)) and len(mc_g) == 5 * 60
+
+
+def test_strict_iterate_raises_on_the_day_of_the_problem():
+    """main.pyx:2017-2018: the reference raises SimulationFailed at the end of the iterate() that hit the
+    problem.  With strict=True this engine does too (default: at the next generate_state()).  Quirk Q8
+    supplies a reproducible failure: a queued agent that is hospitalised the same day is detected twice ->
+    'Wrong state'; oracle B fails on the same day."""
+    import par_backend
+    from reina_model_amd.model import SimulationFailed
+    rng = np.random.default_rng(4242)
+    found = None
+    for case in range(40):   # the extreme random scenarios hit the reference's own failure modes regularly
+        r2 = np.random.default_rng(7000 + case)
+        v, ages, days, ivs, ipc = _random_scenario(r2)
+        total = int(r2.integers(600, 6000))
+        ages = datasets.scaled_population(total)
+        v['infectiousness_multiplier'] = float(r2.uniform(1.0, 3.0))
+        v['hospital_beds'] = 0
+        v['icu_units'] = 0
+        from datetime import date, timedelta
+        d0 = date.fromisoformat(v['start_date'])
+        ivs = list(ivs) + [['import-infections', d0.isoformat(), int(total * 0.5)],
+                           ['test-with-contact-tracing', (d0 + timedelta(days=2)).isoformat(), 100]]
+        cpu = simulation.make_context(v, age_counts=ages, seed=case, interventions=ivs, engine_factory=par_backend.par_engine_factory, strict=True)
+        fail_day = None
+        for d in range(80):
+            try:
+                cpu.iterate()
+            except SimulationFailed as e:
+                fail_day = (d, str(e))
+                break
+        if fail_day is not None:
+            found = (v, ages, ivs, case, fail_day)
+            break
+    assert found is not None, 'no failing scenario among the candidates'
+    v, ages, ivs, case, (day, msg) = found
+    gpu = simulation.make_context(v, age_counts=ages, seed=case, interventions=ivs, strict=True)
+    for d in range(day):
+        gpu.iterate()
+    with pytest.raises(SimulationFailed) as ei:
+        gpu.iterate()
+    assert str(ei.value) == msg
+    # default mode: the same day's iterate() returns, the problem surfaces at the next state export
+    lazy = simulation.make_context(v, age_counts=ages, seed=case, interventions=ivs)
+    for d in range(day + 1):
+        lazy.iterate()
+    with pytest.raises(SimulationFailed):
+        lazy.generate_state()

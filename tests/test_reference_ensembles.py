@@ -1,0 +1,70 @@
+"""The parallel formulation against ENSEMBLES OF THE REAL REFERENCE (tests/golden/ref_ens_*.npz: 128
+cythonsim runs per scenario family, recorded by tests/golden/make_ref_ensemble.py in the build
+container).  This is the link "HIP engine -> reference" of DESIGN.md section 2: the reference's single
+sequential PCG64 stream cannot be replayed in parallel, so the claim is that both engines sample the same
+DISTRIBUTION of trajectories; tests/ref_stats.py states the tolerance (means of every age-group series
+and scalar at 4.5 sigma with no relative slack, variance ratios, KS on per-run outcomes).
+
+  -m gpu       512 HIP-engine seeds per family, the HUS family at BASELINE configs[1] (1 685 983 agents x
+               365 days); plus the NEGATIVE CONTROL: the same comparison with infectiousness_multiplier
+               biased by 3 % must fail.
+  -m "not gpu" oracle B (bit-identical to the HIP engine, tests/test_parity_gpu.py) on the mini families.
+"""
+import pytest
+
+import ref_stats
+
+N_GPU = 512
+N_CPU = 128
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family', ['hus_default', 'mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial'])
+def test_hip_engine_samples_the_reference_distribution(family):
+    par, meta = ref_stats.run_parallel_ensemble(family, range(70000, 70000 + N_GPU))
+    ref, _ = ref_stats.load_ref(family)
+    rep = ref_stats.compare(par, ref, meta)
+    ref_stats.assert_same_distribution(rep, meta)
+    if family == 'hus_default':
+        # the power the comparison has at the BASELINE configuration: cumulative counts are pinned to <= 3 %
+        cum = [m for m in rep['means'] if m[0].endswith(' total') and ' all_infected ' in m[0] and int(m[0].split()[1]) >= 180]
+        assert cum and max(m[4] for m in cum) <= 0.03, max(m[4] for m in cum)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('what,factor', [('infectiousness_multiplier', 1.03), ('infectiousness_multiplier', 0.97)])
+def test_negative_control_a_three_percent_bias_is_detected(what, factor):
+    """the comparison can fail: HUS x 365 d with the transmission probability off by 3 %"""
+    ref, meta = ref_stats.load_ref('hus_default')
+    base = ref_stats.variables_for(meta)
+    par, _ = ref_stats.run_parallel_ensemble('hus_default', range(80000, 80000 + 256), variables_patch={what: base[what] * factor})
+    rep = ref_stats.compare(par, ref, meta)
+    print(ref_stats.tolerance_report(rep, meta))
+    assert len(rep['failures']) > 20, len(rep['failures'])
+    worst = max(abs(m[1]) for m in rep['means'])
+    assert worst > 2 * ref_stats.Z_MAX, worst
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('family', ['mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial'])
+def test_oracle_b_samples_the_reference_distribution(family):
+    import par_backend
+    par, meta = ref_stats.run_parallel_ensemble(family, range(60000, 60000 + N_CPU), engine_factory=par_backend.par_engine_factory)
+    ref, _ = ref_stats.load_ref(family)
+    ref_stats.assert_same_distribution(ref_stats.compare(par, ref, meta), meta)
+
+
+def test_reference_ensembles_are_what_the_generator_describes():
+    """fixture sanity (no engine): shapes, seeds disjoint from the single-run goldens, conservation in
+    every recorded reference run"""
+    import numpy as np
+    for family in ('hus_default', 'mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial'):
+        z, meta = ref_stats.load_ref(family)
+        S, D, _ = z['tot'].shape
+        assert S >= 128 and D == meta['days'] and len(set(z['seeds'].tolist())) == S and z['seeds'].min() >= 1000
+        idx = {n: i for i, n in enumerate(meta['pop13'])}
+        n = sum(meta['age_counts'])
+        t = z['tot'].astype(np.int64)
+        assert np.all(t[..., idx['susceptible']] + t[..., idx['infected']] + t[..., idx['recovered']] + t[..., idx['dead']] == n)
+        assert np.array_equal(z['ag_ck'].sum(axis=3), z['tot'][:, z['ck_days']])
+        assert np.allclose(z['ag_mean'].sum(axis=2), z['tot'].mean(axis=0))
