@@ -55,7 +55,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 HUS_AGENTS = 1685983
-DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_scan', 'k_hosp_contacts', 'k_remote', 'k_install')
+DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install')
 
 
 def scaled_scenario(variables, total_agents):
@@ -146,8 +146,8 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
         infected_on_scan_days=float(inf[days % stride == 0].mean() if (days % stride == 0).any() else inf.mean()),
         mean_infected=float(inf.mean()),
         contacts_per_day=float(contacts[1:].mean() if steps > 1 else contacts.mean()),
-        contacts_on_contact_days=float(contacts[1:][(days[:-1] % stride) == stride // 2].mean()
-                                       if steps > 1 and ((days[:-1] % stride) == stride // 2).any() else contacts.mean()),
+        contacts_on_scan_days=float(contacts[1:][(days[:-1] % stride) == 0].mean()
+                                    if steps > 1 and ((days[:-1] % stride) == 0).any() else contacts.mean()),
         new_infections_per_day=float(new_inf[1:].mean() if steps > 1 else new_inf.mean()),
         final_all_infected=int(tot('all_infected')[-1]),
         peak_infected=int(tot('infected').max()),
@@ -186,9 +186,8 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
     day_bytes = 4.0 * n_agents + 4.0 * st['mean_infected'] + 4.0 * st['contacts_per_day'] + 12.0 * st['new_infections_per_day']
     achieved = day_bytes / (ms_per_step * 1e-3) / 1e9
     alg = {   # algorithmic bytes per launch of the kernels that own a term of B_alg
-        'k_scan': 4.0 * n_agents + 4.0 * st['infected_on_scan_days'],
-        'k_hosp_contacts': 4.0 * st['contacts_on_contact_days'],
-        'k_install': 12.0 * st['new_infections_per_day'],
+        'k_day': 4.0 * n_agents + 4.0 * st['infected_on_scan_days'] + 4.0 * st['contacts_on_scan_days'],
+        'k_hosp_install': 12.0 * st['new_infections_per_day'],
     }
     kernels, ksum = {}, 0.0
     for k in DAY_KERNELS:
@@ -202,7 +201,7 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
             ent['achieved_GBs'] = round(alg[k] / (us * 1e-6) / 1e9, 2)
             ent['frac_of_hbm_peak'] = round(alg[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
         kernels[k] = ent
-    every_day = [k for k in ('k_open', 'k_scan', 'k_hosp_contacts', 'k_install') if k in kernels]
+    every_day = [k for k in ('k_open', 'k_day', 'k_hosp_install') if k in kernels]
     ksum = sum(kernels[k]['avg_launch_us'] for k in every_day)
     for k in every_day:
         kernels[k]['share_of_kernel_time'] = round(kernels[k]['avg_launch_us'] / ksum, 4) if ksum else None
@@ -213,8 +212,8 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
                ms_per_step=round(ms_per_step, 6), kernel_us_per_day=round(ksum, 3), kernels=kernels,
                kernel_timing='HIP events (start/stop of the dispatch packet, launch stream) inside the timed region; on a profiled day '
                              'one kind of kernel is timed: stride %d days per kind' % stride)
-    if 'k_scan' in kernels:
-        out['dominant_kernel'] = dict(name='k_scan', **kernels['k_scan'])
+    if 'k_day' in kernels:
+        out['dominant_kernel'] = dict(name='k_day', **kernels['k_day'])
     if traffic_key is not None:
         out['traffic'], out['traffic_note'] = traffic_for(traffic_key)
     return out

@@ -310,15 +310,16 @@ int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_d
 int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);
 /* timing hooks for bench.py: HIP events on the launch stream around the day's kernels (start / stop
  * timestamps of the kernel's own dispatch packet).
- * enable: 0 off; 1 every kernel of every day; k > 1: one KIND of kernel per profiled day, the kinds taking
- * turns -- k_scan on days with day % k == 0, k_open (+ the occasional kernels: level-1 tracing, vaccination,
- * cross-shard realisation) at k/4, k_hosp_contacts at k/2, k_install at 3k/4 -- so that the cost of
- * timestamped dispatches (a few microseconds each, which matters when a whole day takes 45) stays small.
+ * enable: 0 off; 1 every kernel of every day; k >= 4: one KIND of kernel per profiled day, the kinds taking
+ * turns -- k_day (the stream + contact sampling) on days with day % k == 0, k_open (+ the occasional kernels:
+ * level-1 tracing, vaccination) at k/4, a sharded population's separate event walk and cross-shard
+ * realisation at k/2, k_hosp_install at 3k/4 -- so that the cost of timestamped dispatches (a few
+ * microseconds each, which matters when a whole day takes 40) stays small.
  * reina_profile_read_kernels: summed milliseconds and launch counts per kind since the last read, arrays of
- * REINA_PK_NR; synchronises the device.  reina_profile_read: the k_scan pair of those numbers and the sum
+ * REINA_PK_NR; synchronises the device.  reina_profile_read: the k_day pair of those numbers and the sum
  * over all kinds. */
 enum {
-    REINA_PK_OPEN = 0, REINA_PK_TRACE1, REINA_PK_VACCINATE, REINA_PK_SCAN, REINA_PK_HOSP_CONTACTS, REINA_PK_REMOTE,
+    REINA_PK_OPEN = 0, REINA_PK_TRACE1, REINA_PK_VACCINATE, REINA_PK_DAY, REINA_PK_HOSPITAL, REINA_PK_REMOTE,
     REINA_PK_INSTALL, REINA_PK_NR
 };
 int reina_profile_enable(reina_engine_t *e, int enable);

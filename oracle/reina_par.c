@@ -205,7 +205,7 @@ static uint32_t clamp_days(Par *e, int d) {
 
 /* person_infect (main.pyx:209-235) + Population.infect (:1576-1582) */
 static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant, int32_t src,
-                              int fresh, uint32_t testing_mode) {
+                              int fresh, uint32_t testing_mode, uint32_t src_has_list) {
     int age = age_of(e, t);
     uint32_t w = e->buf.hot[t];
     rp_u4 r = rp_philox(e->k0, e->k1, t, day, RP_P_INFECT, 0);
@@ -226,7 +226,9 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
     if (src >= 0) {
         e->buf.infector[t] = src;
         int old = e->buf.n_infected[src]++;
-        if (e->buf.hot[src] & RH_HASLIST) {
+        /* the source keeps an infectee list: its START-of-day word, carried in the candidate record
+         * (person_expose_others runs before the source's own transition of the day, main.pyx:404-414) */
+        if (src_has_list) {
             if (old >= 64) {
                 set_problem(e, 1 /* TOO_MANY_INFECTEES */);
             } else {
@@ -337,7 +339,7 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
             if (target[j] == 0xFFFFFFFFu) continue;
             uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
             if (e->buf.claim[target[j]] == key) {
-                install_infection(e, target[j], dp->day, variant[j], -1, 1, dp->testing_mode);
+                install_infection(e, target[j], dp->day, variant[j], -1, 1, dp->testing_mode, 0);
                 next_try[j] = 255;
             }
         }
@@ -536,7 +538,7 @@ static void run_scan(Par *e, const reina_day_t *dp) {
                             wi[0] = i;
                             wi[1] = (uint32_t)nr | ((uint32_t)v << 8) | ((uint32_t)age << 16);
                             wi[2] = rp_f2u(src_inf);
-                            wi[3] = 0;
+                            wi[3] = (w & RH_HASLIST) ? 1u : 0u;
                         }
                     }
                 }
@@ -720,7 +722,7 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
             const uint32_t t = target[j];
             if (e->buf.claim[t] != rp_order_key(0, 0xFFFFFu - round, j)) continue;
             next_try[j] = 255;
-            install_infection(e, t, RP_INIT_DAY, 0, -1, j < i_inc, RT_NO_TESTING);
+            install_infection(e, t, RP_INIT_DAY, 0, -1, j < i_inc, RT_NO_TESTING, 0);
             if (j < i_inc) continue;
             uint32_t w = e->buf.hot[t];
             const int age = age_of(e, t);
@@ -862,7 +864,7 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
             uint32_t *cd = e->buf.candidates + 4u * (uint32_t)CTL(e, REINA_L_CAND)++;
             cd[0] = t;
             cd[1] = src;
-            cd[2] = (uint32_t)v;
+            cd[2] = (uint32_t)v | (wi[3] << 8);
             cd[3] = prio;
         }
     }
@@ -921,7 +923,8 @@ static void run_remote(Par *e, const reina_day_t *dp) {
                 uint32_t *cd = e->buf.candidates + 4u * (uint32_t)CTL(e, REINA_L_CAND)++;
                 cd[0] = t;
                 cd[1] = src;
-                cd[2] = v;
+                /* a local stand-in source: its word as it stands now (after the day's bed / ICU walk) */
+                cd[2] = v | ((!(src & RP_REMOTE_SRC) && (e->buf.hot[src] & RH_HASLIST)) ? 0x100u : 0u);
                 cd[3] = prio;
             }
         }
@@ -934,7 +937,7 @@ static void run_install(Par *e, const reina_day_t *dp) {
         if (e->buf.claim[cd[0]] != rp_order_key(dp->day, cd[3], cd[1])) continue;
         if (RH_STATE(e->buf.hot[cd[0]]) != RS_SUSCEPTIBLE) continue; /* duplicate record of the winner */
         int32_t src = (cd[1] & RP_REMOTE_SRC) ? -1 : (int32_t)cd[1];
-        install_infection(e, cd[0], dp->day, cd[2], src, 0, dp->testing_mode);
+        install_infection(e, cd[0], dp->day, cd[2] & 0xFFu, src, 0, dp->testing_mode, (cd[2] >> 8) & 1u);
     }
     /* the free beds / ICU units of all shards are pooled and re-divided for tomorrow (a shard whose share
      * is exhausted gets part of what the others have free; totals are conserved) */

@@ -3,16 +3,15 @@
 // One simulated day (the reference's Context.iterate, cythonsim/main.pyx:2011-2018) is a short
 // sequence of kernels over SoA agent state resident in HBM:
 //
-//   k_prologue  1 workgroup   history snapshot, new beds, imports (claim rounds), daily zeroing,
-//                             vaccination cursor scan                      (main.pyx:1652-1699,560-583)
-//   k_test_*    grid          test queue -> detect, contact tracing level 0 / level 1 (:495-558)
-//   k_scan      grid, stream  every agent's 4-byte hot word: R bookkeeping, state machine,
-//                             contact COUNT draw, hospital events, work items  (:1968-1992,395-438)
-//   k_hospital  1 workgroup   bed / ICU admission in priority order           (:321-367,617-651)
-//   k_contacts  grid          one lane per sampled contact: LDS-staged contact tables, target
-//                             gather, Bernoulli transmission, atomicMin winner claim (:1290-1304,
-//                             1525-1573,908-934)
-//   k_install   grid          winners become INCUBATION (severity + incubation draw) (:209-235)
+//   k_open          first launch: roles by arrival ticket -- history snapshot, new beds, imports (claim rounds),
+//                   daily zeroing | weekly imports | test queue -> detect, contact tracing (main.pyx:1652-1699,495-558)
+//   k_vaccinate     days with a programme: oldest-first cursor scan                            (:560-583)
+//   k_day           every agent's 4-byte hot word streamed once: R bookkeeping, state machine (:1968-1992,395-438),
+//                   and in the same waves the contact sampling of the infectious agents found: LDS-staged
+//                   contact tables, target gather, Bernoulli transmission, atomicMin winner claim
+//                   (:1290-1304,1525-1573,908-934)
+//   k_hosp_install  workgroup 0: bed / ICU admission in priority order (:321-367,617-651) beside workgroups 1..:
+//                   winners become INCUBATION (severity + incubation draw, :209-235), symptom onsets, bookkeeping
 //
 // The path is HBM-bound integer / RNG work: no MFMA.  Wave64 ballots compact rare events,
 // per-lane Philox keys every decision by (agent, day, purpose) so results do not depend on launch
@@ -81,9 +80,9 @@ static int profiled_kind(const reina_engine *e, uint32_t day) {
     if (stride <= 1) return REINA_PK_NR;        // every kernel, every day
     const uint32_t ph = day % stride;
     // the four kernels of every day at evenly spaced phases; the occasional ones ride with k_open's phase
-    if (ph == 0) return REINA_PK_SCAN;
+    if (ph == 0) return REINA_PK_DAY;
     if (ph == stride / 4) return REINA_PK_OPEN;
-    if (ph == stride / 2) return REINA_PK_HOSP_CONTACTS;
+    if (ph == stride / 2) return REINA_PK_HOSPITAL;
     if (ph == stride / 2 + stride / 4) return REINA_PK_INSTALL;
     return -1;
 }
@@ -91,7 +90,8 @@ static bool kind_timed(int today, int kind) {
     if (today < 0) return false;
     if (today == REINA_PK_NR || today == kind) return true;
     // kernels that do not run every day are timed on k_open's days
-    return today == REINA_PK_OPEN && (kind == REINA_PK_TRACE1 || kind == REINA_PK_VACCINATE || kind == REINA_PK_REMOTE);
+    if (today == REINA_PK_HOSPITAL && kind == REINA_PK_REMOTE) return true;
+    return today == REINA_PK_OPEN && (kind == REINA_PK_TRACE1 || kind == REINA_PK_VACCINATE);
 }
 
 #define LAUNCH_TIMED(e, today, kind, kernel, grid, block, lds, stream, ...)                                              \
@@ -239,12 +239,10 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK_OR(hipMalloc(&e->d_ref, sizeof(MemberRef)), free_engine(e));
     HIP_CHECK_OR(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice), free_engine(e));
     HIP_CHECK_OR(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice), free_engine(e));
-    {
-        size_t lds = con_shared_bytes(REINA_MAX_AGES, REINA_MAX_SHARDS);
-        if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
-        HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_contacts),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), free_engine(e));
-    }
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)day_shared_bytes(REINA_LDS_ROWS, REINA_MAX_SHARDS)), free_engine(e));
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)((size_t)REINA_MAX_HOSP_EVENTS * 8)), free_engine(e));
     *out = e;
     return REINA_OK;
 }
@@ -313,22 +311,47 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     e->h_params.n_ranges = t->n_ranges;
     std::memcpy(e->h_params.range_min, t->range_min, sizeof(t->range_min));
     std::memcpy(e->h_params.range_max, t->range_max, sizeof(t->range_max));
-    std::memcpy(e->h_tables.thr, t->threshold, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
-    std::memcpy(e->h_tables.meta, t->meta, sizeof(uint32_t) * A * REINA_MAX_ENTRIES);
-    for (uint32_t a = 0; a < A; a++) {
-        const int cnt = t->count[a];
-        int idx = 0;
-        for (uint32_t b = 0; b < 256; b++) {
-            const uint32_t floor_ = b << 24;
-            while (idx < cnt - 1 && e->h_tables.thr[a][idx] <= floor_) idx++;   // thresholds are non-decreasing
-            e->h_tables.guide[a][b] = (uint8_t)(cnt > 0 ? idx : 0);
+    {   // distinct contact rows (entry count, thresholds, meta words): ages of one class of the matrix share a row
+        Tables &T = e->h_tables;
+        uint32_t n_rows = 0;
+        for (uint32_t a = 0; a < A; a++) {
+            const uint32_t *thr_a = t->threshold + (size_t)a * REINA_MAX_ENTRIES, *meta_a = t->meta + (size_t)a * REINA_MAX_ENTRIES;
+            const size_t used = sizeof(uint32_t) * (size_t)t->count[a];
+            uint32_t r = 0;
+            for (; r < n_rows; r++)
+                if (T.rcount[r] == t->count[a] && std::memcmp(T.thr[r], thr_a, used) == 0 && std::memcmp(T.meta[r], meta_a, used) == 0) break;
+            if (r == n_rows) {
+                std::memcpy(T.thr[r], thr_a, sizeof(uint32_t) * REINA_MAX_ENTRIES);
+                std::memcpy(T.meta[r], meta_a, sizeof(uint32_t) * REINA_MAX_ENTRIES);
+                T.rcount[r] = t->count[a];
+                const int cnt = t->count[a];
+                int idx = 0;
+                for (uint32_t b = 0; b < 256; b++) {
+                    const uint32_t floor_ = b << 24;
+                    while (idx < cnt - 1 && T.thr[r][idx] <= floor_) idx++;   // thresholds are non-decreasing
+                    T.guide[r][b] = (uint8_t)(cnt > 0 ? idx : 0);
+                }
+                n_rows++;
+            }
+            T.row_of_age[a] = (uint8_t)r;
+        }
+        T.n_rows = n_rows;
+        // coarse index -> age map (the age of a sampled target: one table read + 0-1 steps instead of a search)
+        uint32_t shift = 0;
+        while (((uint64_t)e->cfg.n_agents >> shift) >= REINA_AGE_BLOCKS) shift++;
+        T.age_shift = shift;
+        uint32_t a = 0;
+        for (uint32_t b = 0; b < REINA_AGE_BLOCKS; b++) {
+            const uint64_t i = (uint64_t)b << shift;
+            while (a + 1 < A && (uint64_t)e->cfg.age_start[a + 1] <= i) a++;
+            T.age_block[b] = (uint8_t)a;
         }
     }
-    e->uniform_meta = 1;  // every participant age lists the same (place, contact range) sequence?
-    for (uint32_t a = 1; a < A && e->uniform_meta; a++)
-        if (t->count[a] != t->count[0] ||
-            std::memcmp(e->h_tables.meta[a], e->h_tables.meta[0], sizeof(uint32_t) * (size_t)t->count[0]) != 0)
-            e->uniform_meta = 0;
+    e->h_tables.uniform_meta = 1;
+    for (uint32_t r = 1; r < e->h_tables.n_rows && e->h_tables.uniform_meta; r++)
+        if (e->h_tables.rcount[r] != e->h_tables.rcount[0] ||
+            std::memcmp(e->h_tables.meta[r], e->h_tables.meta[0], sizeof(uint32_t) * (size_t)e->h_tables.rcount[0]) != 0)
+            e->h_tables.uniform_meta = 0;
     size_t slot = e->stage.size();
     for (size_t k = 0; k < e->stage.size(); k++)
         if (hipEventQuery(e->stage_ev[k]) == hipSuccess) {
@@ -364,35 +387,16 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     return REINA_OK;
 }
 
-// scanning waves of one engine instance: one 512-agent tile per wave (small populations) up to 8192
-// waves; members of a group share the chip, so each gets its part of ~2048 workgroups and its
-// waves walk several tiles (every later kernel takes the wave count as a parameter)
-// workgroups of the contact sampling for one member (the event workgroup comes on top)
-static uint32_t con_blocks_for(uint32_t scan_waves, uint32_t n_cus, uint32_t K) {
-    uint32_t con_blocks = (scan_waves + CON_WAVES - 1) / CON_WAVES;
-    if (con_blocks > n_cus - 1) con_blocks = n_cus - 1;  // with the event workgroup: one resident wave of workgroups (256 CUs on MI355X)
-    if (K > 1) {  // a group: 256 workgroups for all members together, each staging its tables once for more slices
-        const uint32_t per = n_cus / K > 1u ? n_cus / K - 1u : 1u;
-        if (con_blocks > per) con_blocks = per;
-    }
-    return con_blocks;
-}
-
-static uint32_t scan_blocks_for(uint32_t n_agents, uint32_t K, uint32_t n_cus) {
-    const uint32_t scan_tiles = ((n_agents >> 2) + 127u) / 128u;
-    uint32_t b = (scan_tiles + SCAN_WAVES - 1) / SCAN_WAVES;
+// k_day's workgroups for one engine instance: one 512-agent tile per wave (small populations) up to one
+// workgroup of 16 waves per CU, whose waves then walk several tiles; members of a group share the chip.
+// Every later kernel takes the resulting wave count as a parameter (the per-wave slices of the lists).
+static uint32_t day_blocks_for(uint32_t n_agents, uint32_t K, uint32_t n_cus) {
+    const uint32_t tiles = ((n_agents >> 2) + 127u) / 128u;
+    uint32_t b = (tiles + DAY_WAVES - 1) / DAY_WAVES;
     if (b < 1) b = 1;
-    if (b > REINA_MAX_SCAN_WAVES / SCAN_WAVES) b = REINA_MAX_SCAN_WAVES / SCAN_WAVES;
-    if (K > 1) {
-        uint32_t per = (REINA_MAX_SCAN_WAVES / SCAN_WAVES) / K;
-        if (per < 16) per = 16;
-        if (b > per) b = per;
-    }
-    // The scanning waves' slices are dealt out to the contact waves round robin: with 8192 slices for 4080
-    // contact waves, 32 waves would work a third slice while 254 CUs idle (+50 % on the kernel).  With two or
-    // more slices per contact wave the slice count is therefore rounded down to a multiple of the contact waves.
-    const uint32_t unit = con_blocks_for(b * SCAN_WAVES, n_cus, K) * CON_WAVES / SCAN_WAVES;   // blocks per "one slice each"
-    if (unit > 0 && b >= 2 * unit) b -= b % unit;
+    uint32_t cap = K > 1 ? (n_cus / K > 0 ? n_cus / K : 1u) : n_cus;
+    if (cap > REINA_MAX_SCAN_WAVES / DAY_WAVES) cap = REINA_MAX_SCAN_WAVES / DAY_WAVES;
+    if (b > cap) b = cap;
     return b;
 }
 
@@ -435,22 +439,19 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         }
     }
     if (dp.n_vaccinations) LAUNCH_TIMED(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
-    // scan geometry: tiles of 512 agents, as many waves as tiles (small populations) up to 8192
+    // the stream: tiles of 512 agents, as many waves as tiles (small populations) up to 16 per CU
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-    const uint32_t scan_blocks = scan_blocks_for(N, K, e->n_cus);
-    const uint32_t scan_waves = scan_blocks * SCAN_WAVES;
-    LAUNCH_TIMED(e, today, REINA_PK_SCAN, k_scan, dim3(scan_blocks, K), dim3(SCAN_THREADS), 0, s, refs, dp);
-    {   // bed / ICU events (workgroup 0, latency-bound) beside the contact sampling (workgroups 1..)
-        const uint32_t con_blocks = con_blocks_for(scan_waves, e->n_cus, K);
-        size_t lds = con_shared_bytes(e->cfg.nr_ages, e->cfg.n_shards);
-        if (lds < (size_t)REINA_MAX_HOSP_EVENTS * 8) lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
-        // slices per contact wave and step: 1 while every slice has a wave of its own, up to 8 otherwise
-        uint32_t group_slices = scan_waves / (con_blocks * CON_WAVES);
-        if (group_slices < 4) group_slices = 1;   // (measured: grouping 2 dense slices of a 50 M population costs more than it fills)
-        if (group_slices > 8) group_slices = 8;
-        LAUNCH_TIMED(e, today, REINA_PK_HOSP_CONTACTS, k_hosp_contacts, dim3(con_blocks + 1, K), dim3(CON_THREADS), lds, s, refs, dp,
-                     scan_waves, scan_tiles, e->uniform_meta, group_slices);
+    const uint32_t day_blocks = day_blocks_for(N, K, e->n_cus);
+    const uint32_t scan_waves = day_blocks * DAY_WAVES;
+    {
+        uint32_t lds_rows = K > 1 ? e->group_lds_rows : e->h_tables.n_rows;   // (a member stages min(its own rows, lds_rows))
+        if (lds_rows > REINA_LDS_ROWS) lds_rows = REINA_LDS_ROWS;
+        LAUNCH_TIMED(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, e->cfg.n_shards), s,
+                     refs, dp, lds_rows);
     }
+    if (e->cfg.n_shards > 1)   // the event walk before the all-reduce, which carries the shards' free capacity
+        LAUNCH_TIMED(e, today, REINA_PK_HOSPITAL, k_hosp_install, dim3(1, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
+                     refs, dp, scan_waves, scan_tiles, 1);
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
@@ -458,16 +459,18 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
 static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, hipStream_t s) {
     const uint32_t N = e->cfg.n_agents;
     const int today = profiled_kind(e, dp.day);
-    if (e->cfg.n_shards > 1)
+    const bool sharded = e->cfg.n_shards > 1;
+    if (sharded)
         LAUNCH_TIMED(e, today, REINA_PK_REMOTE, k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-        const uint32_t scan_blocks = scan_blocks_for(N, K, e->n_cus);
-        int ig = grid_for(N / 64 + 1, 256, 512) * 2;  // even: candidates / deferred lists
-        // (groups: 512 workgroups for all members together -- measured on 8 / 32 / 128 HUS-sized members against
-        // 256, 1024, 2048 and 4096: every workgroup pays its prologue and its histogram flush)
-        if (K > 1 && ig > (int)(512 / K)) ig = (int)(512 / K) >= 2 ? ((int)(512 / K) & ~1) : 2;
-        LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_install, dim3(ig, K), dim3(256), 0, s, refs, dp, scan_blocks * SCAN_WAVES, scan_tiles);
+        const uint32_t scan_waves = day_blocks_for(N, K, e->n_cus) * DAY_WAVES;
+        int ig = grid_for(N / 64 + 1, HOSP_THREADS, 128) * 2;  // even: candidates / deferred lists
+        // (groups: 128 workgroups for all members together -- every workgroup pays its prologue and its histogram flush)
+        if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 2;
+        // unsharded: workgroup 0 walks the bed / ICU events beside the installs
+        LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig + (sharded ? 0 : 1), K), dim3(HOSP_THREADS),
+                     sharded ? 0 : (size_t)REINA_MAX_HOSP_EVENTS * 8, s, refs, dp, scan_waves, scan_tiles, sharded ? 2 : 0);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
@@ -603,7 +606,6 @@ int reina_group_upload_contact_tables(reina_group_t *g, const reina_contact_tabl
         std::memcpy(reinterpret_cast<char *>(&m->h_params) + DP_TAB1_BEGIN, reinterpret_cast<const char *>(&e0->h_params) + DP_TAB1_BEGIN,
                     sizeof(DevParams) - DP_TAB1_BEGIN);
         std::memcpy(&m->h_tables, &e0->h_tables, sizeof(Tables));
-        m->uniform_meta = e0->uniform_meta;
     }
     hipLaunchKernelGGL(k_group_tables, dim3(32, K - 1), dim3(256), 0, (hipStream_t)stream, g->d_refs);
     HIP_CHECK(hipGetLastError());
@@ -619,6 +621,9 @@ int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_d
     HIP_CHECK(hipMemcpyAsync(g->d_refs, g->h_refs.data(), sizeof(MemberRef) * K, hipMemcpyHostToDevice, s));
     reina_engine_t *e0 = g->members[0];
     bool tested = false;  // the test-queue kernels run for all members once any member ever tested
+    e0->group_lds_rows = 0;
+    for (auto m : g->members)
+        if (m->h_tables.n_rows > e0->group_lds_rows) e0->group_lds_rows = m->h_tables.n_rows;
     for (auto m : g->members) tested = tested || m->testing_ever;
     for (uint32_t d = 0; d < n_days; d++) tested = tested || days[d].testing_mode != RT_NO_TESTING;
     e0->testing_ever = e0->testing_ever || (tested && n_days == 0);
@@ -674,8 +679,8 @@ int reina_profile_read(reina_engine_t *e, double *scan_ms_total, uint64_t *scan_
     uint64_t n[REINA_PK_NR];
     const int rc = reina_profile_read_kernels(e, ms, n);
     if (rc) return rc;
-    if (scan_ms_total) *scan_ms_total = ms[REINA_PK_SCAN];
-    if (scan_launches) *scan_launches = n[REINA_PK_SCAN];
+    if (scan_ms_total) *scan_ms_total = ms[REINA_PK_DAY];
+    if (scan_launches) *scan_launches = n[REINA_PK_DAY];
     if (all_ms_total) {   // every timed launch of every kind
         *all_ms_total = 0;
         for (int k = 0; k < REINA_PK_NR; k++) *all_ms_total += ms[k];

@@ -44,7 +44,7 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 32
 L_HOSP_PEAK = 12   # control word: event count of the busiest day that needed several priority ranges
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
-PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_scan', 'k_hosp_contacts', 'k_remote', 'k_install')
+PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install')
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
                  'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',

@@ -619,7 +619,9 @@ def test_driver_contract_on_the_hip_engine():
 
     df_s, adf_s = simulation.simulate_individuals(v, age_counts=ages, step_callback=cb, callback_day_interval=7)
     assert seen == list(range(7, 90, 7)) + [90]
-    pd.testing.assert_frame_equal(df_s[cols], df_c[cols])
+    # (`r` is the int 0 until more than 5 infectors were seen, main.pyx:1817: an object column in the frame
+    # assembled from the whole history, a float column once NaN-padded callback frames were involved)
+    pd.testing.assert_frame_equal(df_s[cols].astype({'r': float}), df_c[cols].astype({'r': float}))
     pd.testing.assert_frame_equal(adf_s, adf_c)
     calls = []
     with pytest.raises(simulation.ExecutionInterrupted):
