@@ -91,8 +91,11 @@ enum {
     REINA_L_HOSP_PEAK,                                  /* busiest multi-range day so far: its bed / ICU event count (0: every day fit one pass) */
     REINA_L_OPEN_TICKET,                                /* arrival tickets of the day-opening launch: 0 opens the day, 1 places the weekly
                                                            imports, 2.. work off the test queue; reset by the launch's last arrival */
-    REINA_L_VACC_CURSOR = 16,                           /* [REINA_MAX_VACCINATIONS] */
-    REINA_L_NR = 32
+    REINA_L_BEDS_OPEN, REINA_L_ICU_OPEN,                /* free beds / ICU units when the day opened (after new capacity was added) */
+    REINA_L_EV_HOSPITALIZE, REINA_L_EV_TO_ICU,          /* the day's admission / ICU-transfer requests (counted by the stream): with the two words
+                                                           above they say whether a resource can run out today, i.e. whether event ORDER matters */
+    REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
+    REINA_L_NR = 48
 };
 
 /* words of buffers.hosp_events for a day capacity of `cap` events: sort scratch, range bases, two key lists */

@@ -449,9 +449,12 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         LAUNCH_TIMED(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, e->cfg.n_shards), s,
                      refs, dp, lds_rows);
     }
-    if (e->cfg.n_shards > 1)   // the event walk before the all-reduce, which carries the shards' free capacity
-        LAUNCH_TIMED(e, today, REINA_PK_HOSPITAL, k_hosp_install, dim3(1, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
+    if (e->cfg.n_shards > 1) {  // the event walk before the all-reduce, which carries the shards' free capacity
+        // (one workgroup walks in order when a resource can run out; otherwise all of them share the events)
+        const int hg = grid_for(N / 4096 + 1, HOSP_THREADS, 64);
+        LAUNCH_TIMED(e, today, REINA_PK_HOSPITAL, k_hosp_install, dim3(hg, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
                      refs, dp, scan_waves, scan_tiles, 1);
+    }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }

@@ -41,7 +41,7 @@ S_DAILY_CONTACTS = 16
 S_INFECTED_BY_VARIANT = 24
 S_NR = 32
 COUNTER_WORDS = C_NR * MAX_AGES + S_NR
-L_NR = 32
+L_NR = 48
 L_HOSP_PEAK = 12   # control word: event count of the busiest day that needed several priority ranges
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
 PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install')

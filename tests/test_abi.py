@@ -59,3 +59,49 @@ def test_product_package_never_references_the_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text, fn
                 assert 'libreina_par' not in text and 'libreina_seq' not in text, fn
+
+
+def test_kernels_fit_the_lds_they_ask_for():
+    """static + dynamic LDS of the two big kernels within a CU's 160 KB (hipFuncSetAttribute fails at engine
+    creation otherwise -- on the GPU box only), and no kernel spills vector registers to scratch; read from
+    the code object's metadata"""
+    import shutil
+    import subprocess
+    import tempfile
+    from reina_model_amd import build
+    tools = '/opt/rocm/lib/llvm/bin'
+    if not os.path.exists(os.path.join(tools, 'llvm-objdump')):
+        pytest.skip('no llvm tools')
+    build.build()
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, 'lib.so')
+        shutil.copy(build.LIB, so)
+        subprocess.run([os.path.join(tools, 'llvm-objdump'), '--offloading', so], check=True, capture_output=True, cwd=tmp)
+        co = [f for f in os.listdir(tmp) if 'gfx950' in f]
+        assert co, os.listdir(tmp)
+        notes = subprocess.run([os.path.join(tools, 'llvm-readelf'), '--notes', os.path.join(tmp, co[0])],
+                               check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    name = None
+    fields = {}
+    for line in notes.splitlines():
+        line = line.strip()
+        for key in ('.group_segment_fixed_size:', '.vgpr_spill_count:', '.private_segment_fixed_size:', '.vgpr_count:'):
+            if line.startswith(key):
+                fields[key] = int(line.split()[-1])
+        if line.startswith('.name:'):
+            name = line.split()[-1]
+        if line.startswith('.wavefront_size:') and name:
+            kernels[name] = fields
+            fields, name = {}, None
+    day = [v for k, v in kernels.items() if 'k_day' in k]
+    hosp = [v for k, v in kernels.items() if 'k_hosp_install' in k]
+    assert len(day) == 1 and len(hosp) == 1, sorted(kernels)
+    LDS = 160 * 1024
+    # dynamic requests: reina_hip.hip (day_shared_bytes(REINA_LDS_ROWS, sharded), REINA_MAX_HOSP_EVENTS * 8)
+    assert hosp[0]['.group_segment_fixed_size:'] + eng.MAX_HOSP_EVENTS * 8 <= LDS
+    text = open(os.path.join(ROOT, 'reina_model_amd', 'csrc', 'k_contacts.inc')).read()
+    assert 'struct DayShared' in text
+    assert day[0]['.group_segment_fixed_size:'] <= 1024     # (its big arrays are carved from the dynamic part)
+    for k, v in kernels.items():
+        assert v.get('.vgpr_spill_count:', 0) == 0, (k, v)
