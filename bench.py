@@ -55,7 +55,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 HUS_AGENTS = 1685983
-DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install')
+DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install')
 
 
 def scaled_scenario(variables, total_agents):
@@ -201,7 +201,7 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
             ent['achieved_GBs'] = round(alg[k] / (us * 1e-6) / 1e9, 2)
             ent['frac_of_hbm_peak'] = round(alg[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
         kernels[k] = ent
-    every_day = [k for k in ('k_open', 'k_day', 'k_hosp_install') if k in kernels]
+    every_day = [k for k in ('k_open', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install', 'k_hosp_sort', 'k_hosp_walk') if k in kernels]
     ksum = sum(kernels[k]['avg_launch_us'] for k in every_day)
     for k in every_day:
         kernels[k]['share_of_kernel_time'] = round(kernels[k]['avg_launch_us'] / ksum, 4) if ksum else None

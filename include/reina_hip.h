@@ -88,7 +88,8 @@ enum {
     REINA_L_DAY_OPEN,                                   /* day + 1 once that day's snapshot / zeroing is done */
     REINA_L_TRACE_DONE,                                 /* level-0 tracing workgroups finished today (folded level 1) */
     REINA_L_CAND_OVF,                                   /* candidate records that did not fit their slice's region today */
-    REINA_L_HOSP_PEAK,                                  /* busiest multi-range day so far: its bed / ICU event count (0: every day fit one pass) */
+    REINA_L_HOSP_PEAK,                                  /* busiest day so far on which a bed or ICU unit could run out (the events' order
+                                                           mattered): its bed / ICU event count */
     REINA_L_OPEN_TICKET,                                /* arrival tickets of the day-opening launch: 0 opens the day, 1 places the weekly
                                                            imports, 2.. work off the test queue; reset by the launch's last arrival */
     REINA_L_BEDS_OPEN, REINA_L_ICU_OPEN,                /* free beds / ICU units when the day opened (after new capacity was added) */
@@ -98,15 +99,34 @@ enum {
     REINA_L_NR = 48
 };
 
-/* words of buffers.hosp_events for a day capacity of `cap` events: sort scratch, range bases, two key lists */
-#define REINA_HOSP_EVENT_WORDS(cap) (REINA_MAX_HOSP_EVENTS + 1024 + 2 * ((cap) > REINA_MAX_HOSP_EVENTS ? (cap) : REINA_MAX_HOSP_EVENTS))
+/* The day's bed / ICU events are kept in buckets by priority range (buffers.hosp_events, 64-bit words):
+ * R = REINA_HOSP_RANGES(n_agents) buckets of REINA_HOSP_BUCKET_CAP(n_agents, max_hosp_events) keys, preceded by
+ * R / 2 words of bucket counts and 2 R words of per-bucket aggregates.  A population of at most
+ * REINA_HOSP_SMALL_AGENTS agents has its events walked by one workgroup (at most REINA_MAX_HOSP_EVENTS - 1024 a day);
+ * a larger one by one workgroup per bucket. */
+#define REINA_HOSP_MAX_RANGES 1024
+#define REINA_HOSP_SMALL_AGENTS (128u * REINA_MAX_HOSP_EVENTS)
+static inline uint32_t REINA_HOSP_RANGES(uint32_t n_agents) {
+    uint32_t r = 16;
+    while (r < REINA_HOSP_MAX_RANGES && (uint64_t)r * 65536u < n_agents) r <<= 1;
+    return r;
+}
+static inline uint32_t REINA_HOSP_BUCKET_CAP(uint32_t n_agents, uint32_t max_hosp_events) {
+    const uint32_t cap = max_hosp_events > REINA_MAX_HOSP_EVENTS ? max_hosp_events : REINA_MAX_HOSP_EVENTS;
+    return 2u * (cap / REINA_HOSP_RANGES(n_agents)) + 64u;   /* twice the mean at the day capacity: > 10 sigma */
+}
+static inline size_t REINA_HOSP_EVENT_WORDS(uint32_t n_agents, uint32_t max_hosp_events) {
+    const size_t r = REINA_HOSP_RANGES(n_agents);
+    return r / 2 + 2 * r + r * (size_t)REINA_HOSP_BUCKET_CAP(n_agents, max_hosp_events);
+}
 
 typedef struct {
     uint32_t n_agents;        /* agents of this engine instance, sorted by age */
     uint32_t nr_ages;         /* A */
     uint32_t nr_variants;     /* V */
-    uint32_t max_hosp_events; /* bed / ICU events one day may hold (0 or less than REINA_MAX_HOSP_EVENTS = that number,
-                                 which one walk holds in LDS; busier days are walked in priority ranges) */
+    uint32_t max_hosp_events; /* bed / ICU events one day may hold (0 or less than REINA_MAX_HOSP_EVENTS = that number):
+                                 sizes the event buckets; more than REINA_HOSP_BUCKET_CAP keys in one bucket, or more
+                                 than one workgroup's walk holds in a small population, fail the run (problem 103) */
     uint64_t seed;            /* Philox key (random_seed of Context, main.pyx:1759); same on all shards,
                                  the engine mixes the rank in */            /* Philox key (random_seed of Context, main.pyx:1759) */
     uint32_t max_work_items;  /* capacity of work_items (records) */
@@ -181,15 +201,15 @@ typedef struct {
     uint64_t *claim;          /* [N] winner-selection keys, init 0xFF..FF */
     int32_t *counters;        /* [REINA_COUNTER_WORDS] */
     int32_t *control;         /* [REINA_L_NR] */
-    uint32_t *work_items;     /* [max_work_items * 4] (src, nr | variant << 8 | age << 16, src_inf bits, pad);
-                                 max_work_items >= n_agents + 1024 */
+    uint32_t *work_items;     /* [max_work_items * 4]: the second half holds the per-slice lists of symptom onsets
+                                 (agent, word); max_work_items >= n_agents + 1024 */
     uint32_t *candidates;     /* [max_candidates * 4] (target, src, variant, prio); target 0xFFFFFFFF = hole.
                                  [0, max_work_items): per-slice regions; above: candidates realised from
                                  cross-shard pressure. max_candidates >= max_work_items + expected remote */
     uint32_t *queue0;         /* [max_queue] testing queue, even days */
     uint32_t *queue1;         /* [max_queue] testing queue, odd days */
     uint32_t *level1;         /* [max_queue] contact-tracing level-1 work list */
-    uint64_t *hosp_events;    /* [REINA_HOSP_EVENT_WORDS(max_hosp_events)]: scratch of the event walk */
+    uint64_t *hosp_events;    /* [REINA_HOSP_EVENT_WORDS(n_agents, max_hosp_events)]: the day's bed / ICU events by priority range */
     int32_t *pressure;        /* [REINA_PRESSURE_WORDS] cross-shard infection pressure of the day:
                                  [dest shard][contact range][variant] = transmissible contacts aimed at
                                  agents of another shard. Filled by reina_step_day_begin, summed over
@@ -208,9 +228,6 @@ typedef struct {
     uint32_t *scan_lists;     /* [4 * max_work_items] two lists of (agent, kind) pairs written by the
                                  scan: hospital events, then bookkeeping (R statistics, home
                                  recoveries / deaths). The other two lists live in work_items. */
-    uint32_t *sus_bits;       /* [ceil(N/32)] bit i set <=> agent i is SUSCEPTIBLE (never infected):
-                                 the only thing a sampled contact needs to know about its target
-                                 (person_expose, main.pyx:239), 1 bit instead of a 64-byte struct */
 } reina_buffers_t;
 
 /* `pre_init` = 1 for batches that come from an `import-infections` intervention: the reference
@@ -315,15 +332,15 @@ int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);
  * timestamps of the kernel's own dispatch packet).
  * enable: 0 off; 1 every kernel of every day; k >= 4: one KIND of kernel per profiled day, the kinds taking
  * turns -- k_day (the stream + contact sampling) on days with day % k == 0, k_open (+ the occasional kernels:
- * level-1 tracing, vaccination) at k/4, a sharded population's separate event walk and cross-shard
- * realisation at k/2, k_hosp_install at 3k/4 -- so that the cost of timestamped dispatches (a few
+ * level-1 tracing, vaccination) at k/4, the event-walk launches (a sharded population's, a large population's
+ * k_hosp_sort / k_hosp_walk) and the cross-shard realisation at k/2, k_hosp_install at 3k/4 -- so that the cost of timestamped dispatches (a few
  * microseconds each, which matters when a whole day takes 40) stays small.
  * reina_profile_read_kernels: summed milliseconds and launch counts per kind since the last read, arrays of
  * REINA_PK_NR; synchronises the device.  reina_profile_read: the k_day pair of those numbers and the sum
  * over all kinds. */
 enum {
-    REINA_PK_OPEN = 0, REINA_PK_TRACE1, REINA_PK_VACCINATE, REINA_PK_DAY, REINA_PK_HOSPITAL, REINA_PK_REMOTE,
-    REINA_PK_INSTALL, REINA_PK_NR
+    REINA_PK_OPEN = 0, REINA_PK_TRACE1, REINA_PK_VACCINATE, REINA_PK_DAY, REINA_PK_HOSPITAL, REINA_PK_HOSP_SORT,
+    REINA_PK_HOSP_WALK, REINA_PK_REMOTE, REINA_PK_INSTALL, REINA_PK_NR
 };
 int reina_profile_enable(reina_engine_t *e, int enable);
 int reina_profile_read_kernels(reina_engine_t *e, double *ms_total, uint64_t *launches);

@@ -138,8 +138,6 @@ int par_init_state(Par *e, int32_t beds, int32_t icu, void *stream) {
         e->buf.mirror_meta[c] = e->cfg.mirror_slots < RP_MIRROR_MIN_SLOTS ? e->cfg.mirror_slots : RP_MIRROR_MIN_SLOTS;
         e->buf.mirror_meta[REINA_MIRROR_CELLS + c] = 0;
     }
-    for (uint32_t k = 0; k < (N + 31) / 32 + 1; k++) e->buf.sus_bits[k] = 0;
-    for (uint32_t i = 0; i < N; i++) e->buf.sus_bits[i >> 5] |= 1u << (i & 31);
     memset(e->buf.counters, 0, sizeof(int32_t) * REINA_COUNTER_WORDS);
     memset(e->buf.control, 0, sizeof(int32_t) * REINA_L_NR);
     for (uint32_t a = 0; a < e->cfg.nr_ages; a++)
@@ -222,7 +220,6 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
                   /* (a FRESH agent of the initial condition sits out the scan of day 0 first) */
                   RH_DAYS_FIELD(dl, (fresh && day == RP_INIT_DAY) ? day + 1u : day);
     e->buf.hot[t] = nw;
-    e->buf.sus_bits[t >> 5] &= ~(1u << (t & 31));
     if (src >= 0) {
         e->buf.infector[t] = src;
         int old = e->buf.n_infected[src]++;
@@ -844,8 +841,11 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
                 continue;
             }
             if (end <= start) continue;
+            /* a draw that is not below the source's LARGEST possible transmission probability cannot infect
+             * whoever is met: skip the look at the target (same outcome, far fewer random reads on the host) */
+            if (!rp_chance(src_inf * e->psus_max[v] * d->infectiousness_multiplier[v], r.v[2])) continue;
             uint32_t t = start + (r.v[1] / G) % (end - start);
-            if (!((e->buf.sus_bits[t >> 5] >> (t & 31)) & 1u)) continue;
+            if (RH_STATE(e->buf.hot[t]) != RS_SUSCEPTIBLE) continue;   /* person_expose, main.pyx:239 */
             int age_t = age_of(e, t);
             float p = src_inf * d->p_susceptibility[v][age_t] * d->infectiousness_multiplier[v];
             if (!rp_chance(p, r.v[2])) continue;
@@ -886,7 +886,7 @@ static void run_remote(Par *e, const reina_day_t *dp) {
                 if (end <= start) continue;
                 rp_u4 r = rp_philox(e->k0, e->k1, (uint32_t)k, dp->day, RP_P_REMOTE, rg | (v << 8));
                 uint32_t t = start + r.v[0] % (end - start);
-                if (!((e->buf.sus_bits[t >> 5] >> (t & 31)) & 1u)) continue;
+                if (RH_STATE(e->buf.hot[t]) != RS_SUSCEPTIBLE) continue;   /* person_expose, main.pyx:239 */
                 int age_t = age_of(e, t);
                 float p = d->p_susceptibility[v][age_t] / e->psus_max[v];
                 if (!rp_chance(p, r.v[1])) continue;

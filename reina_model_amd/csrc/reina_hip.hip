@@ -90,7 +90,7 @@ static bool kind_timed(int today, int kind) {
     if (today < 0) return false;
     if (today == REINA_PK_NR || today == kind) return true;
     // kernels that do not run every day are timed on k_open's days
-    if (today == REINA_PK_HOSPITAL && kind == REINA_PK_REMOTE) return true;
+    if (today == REINA_PK_HOSPITAL && (kind == REINA_PK_REMOTE || kind == REINA_PK_HOSP_SORT || kind == REINA_PK_HOSP_WALK)) return true;
     return today == REINA_PK_OPEN && (kind == REINA_PK_TRACE1 || kind == REINA_PK_VACCINATE);
 }
 
@@ -234,6 +234,16 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     }
     e->h_params.max_queue = cfg->max_queue;
     e->h_params.max_hosp_events = cfg->max_hosp_events > REINA_MAX_HOSP_EVENTS ? cfg->max_hosp_events : REINA_MAX_HOSP_EVENTS;
+    e->h_params.hosp_ranges = REINA_HOSP_RANGES(cfg->n_agents);
+    e->h_params.hosp_range_bits = 0;
+    while ((1u << e->h_params.hosp_range_bits) < e->h_params.hosp_ranges) e->h_params.hosp_range_bits++;
+    e->h_params.hosp_bucket_cap = REINA_HOSP_BUCKET_CAP(cfg->n_agents, cfg->max_hosp_events);
+    e->h_params.hosp_parallel = cfg->n_agents > REINA_HOSP_SMALL_AGENTS ? 1u : 0u;
+    if (e->h_params.hosp_parallel && e->h_params.hosp_bucket_cap > HOSP_P_THREADS * HOSP_P_E) {
+        g_last_error = "max_hosp_events too large for this population: a bucket of the event walk holds at most 4096 keys";
+        delete e;
+        return REINA_E_INVALID;
+    }
     HIP_CHECK_OR(hipMalloc(&e->d_params, sizeof(DevParams)), free_engine(e));
     HIP_CHECK_OR(hipMalloc(&e->d_tables, sizeof(Tables)), free_engine(e));
     HIP_CHECK_OR(hipMalloc(&e->d_ref, sizeof(MemberRef)), free_engine(e));
@@ -400,6 +410,14 @@ static uint32_t day_blocks_for(uint32_t n_agents, uint32_t K, uint32_t n_cus) {
     return b;
 }
 
+// the ordered walk of a large population's bed / ICU events: one workgroup per priority bucket, two launches
+// (both return at once on a day on which no resource can run out)
+static void launch_parallel_walk(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, int today, hipStream_t s) {
+    const uint32_t R = e->h_params.hosp_ranges;
+    LAUNCH_TIMED(e, today, REINA_PK_HOSP_SORT, k_hosp_sort, dim3(R, K), dim3(HOSP_P_THREADS), 0, s, refs, dp);
+    LAUNCH_TIMED(e, today, REINA_PK_HOSP_WALK, k_hosp_walk, dim3(R, K), dim3(HOSP_P_THREADS), 0, s, refs, dp);
+}
+
 // One day's launches for K engine instances at once (K = 1: a single engine; K > 1: a group of
 // identically configured engines, one launch per phase for all of them, member = blockIdx.y).
 // `e` is the representative engine: geometry, scenario flags, optional second stream.
@@ -449,11 +467,12 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         LAUNCH_TIMED(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, e->cfg.n_shards), s,
                      refs, dp, lds_rows);
     }
-    if (e->cfg.n_shards > 1) {  // the event walk before the all-reduce, which carries the shards' free capacity
-        // (one workgroup walks in order when a resource can run out; otherwise all of them share the events)
+    if (e->cfg.n_shards > 1) {  // the bed / ICU events before the all-reduce, which carries the shards' free capacity
         const int hg = grid_for(N / 4096 + 1, HOSP_THREADS, 64);
-        LAUNCH_TIMED(e, today, REINA_PK_HOSPITAL, k_hosp_install, dim3(hg, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
-                     refs, dp, scan_waves, scan_tiles, 1);
+        const bool par = e->h_params.hosp_parallel != 0;
+        LAUNCH_TIMED(e, today, REINA_PK_HOSPITAL, k_hosp_install, dim3(hg, K), dim3(HOSP_THREADS), par ? 0 : (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
+                     refs, dp, scan_waves, scan_tiles, par ? HI_EVENTS : (HI_HOSP_WG | HI_EVENTS));
+        if (par) launch_parallel_walk(e, refs, K, dp, today, s);
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
@@ -471,9 +490,19 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         int ig = grid_for(N / 64 + 1, HOSP_THREADS, 128) * 2;  // even: candidates / deferred lists
         // (groups: 128 workgroups for all members together -- every workgroup pays its prologue and its histogram flush)
         if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 2;
-        // unsharded: workgroup 0 walks the bed / ICU events beside the installs
-        LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig + (sharded ? 0 : 1), K), dim3(HOSP_THREADS),
-                     sharded ? 0 : (size_t)REINA_MAX_HOSP_EVENTS * 8, s, refs, dp, scan_waves, scan_tiles, sharded ? 2 : 0);
+        const bool par = e->h_params.hosp_parallel != 0;
+        if (sharded) {
+            LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig, K), dim3(HOSP_THREADS), 0, s, refs, dp, scan_waves, scan_tiles, HI_INSTALL);
+        } else if (par) {
+            // a large population: the events of a day on which order matters are walked by one workgroup per bucket
+            LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig, K), dim3(HOSP_THREADS), 0, s, refs, dp, scan_waves, scan_tiles,
+                         HI_INSTALL | HI_EVENTS);
+            launch_parallel_walk(e, refs, K, dp, today, s);
+        } else {
+            // workgroup 0 walks the bed / ICU events of a day on which order matters, beside the installs
+            LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig + 1, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
+                         refs, dp, scan_waves, scan_tiles, HI_HOSP_WG | HI_INSTALL | HI_EVENTS);
+        }
     }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;

@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(HERE, 'csrc', 'libreina_hip.so')
+# (REINA_HIP_LIB: a diagnostic build of the same sources, e.g. with in-kernel stamps -- tools/ only)
+HIP_LIB_PATH = os.environ.get('REINA_HIP_LIB') or os.path.join(HERE, 'csrc', 'libreina_hip.so')
 
 MAX_AGES = 128
 MAX_VARIANTS = 4
@@ -44,7 +45,7 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 48
 L_HOSP_PEAK = 12   # control word: event count of the busiest day that needed several priority ranges
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
-PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install')
+PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install')
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
                  'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
@@ -93,7 +94,7 @@ class ContactTablesABI(ctypes.Structure):
 
 BUFFER_FIELDS = ('hot', 'infector', 'n_infected', 'onset_days', 'vacc_day', 'first_infectee',
                  'next_sibling', 'claim', 'counters', 'control', 'work_items', 'candidates',
-                 'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'mirror_meta', 'work_counts', 'scan_lists', 'sus_bits')
+                 'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'mirror_meta', 'work_counts', 'scan_lists')
 
 
 class Buffers(ctypes.Structure):
@@ -124,6 +125,15 @@ class Day(ctypes.Structure):
                 ('import_batches', ImportBatch * MAX_IMPORT_BATCHES),
                 ('vaccinations', Vaccination * MAX_VACCINATIONS),
                 ('history_row', ctypes.c_void_p)]
+
+
+def hosp_event_words(n_agents, max_hosp_events):
+    """include/reina_hip.h: REINA_HOSP_EVENT_WORDS (64-bit words of buffers.hosp_events)"""
+    r = 16
+    while r < 1024 and r * 65536 < n_agents:
+        r <<= 1
+    cap = 2 * (max(MAX_HOSP_EVENTS, max_hosp_events) // r) + 64
+    return r // 2 + 2 * r + r * cap
 
 
 def bind_abi(lib, prefix):
@@ -243,14 +253,13 @@ class Engine:
             candidates=a.zeros(4 * config.max_candidates, np.uint32),
             queue0=a.zeros(config.max_queue, np.uint32), queue1=a.zeros(config.max_queue, np.uint32),
             level1=a.zeros(config.max_queue, np.uint32),
-            # [sort scratch][range bases][the day's keys in list order][the same grouped by priority range]
-            hosp_events=a.zeros(MAX_HOSP_EVENTS + 1024 + 2 * max(MAX_HOSP_EVENTS, config.max_hosp_events), np.uint64),
+            # the day's bed / ICU events by priority range: [bucket counts][bucket aggregates][keys]
+            hosp_events=a.zeros(hosp_event_words(n, config.max_hosp_events), np.uint64),
             pressure=a.zeros(PRESSURE_WORDS, np.int32),
             mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 32, np.uint64),
             mirror_meta=a.zeros(2 * MAX_RANGES * MAX_VARIANTS, np.uint32),
             work_counts=a.zeros(5 * MAX_SCAN_WAVES, np.uint32),
             scan_lists=a.zeros(4 * config.max_work_items, np.uint32),
-            sus_bits=a.zeros((n + 31) // 32 + 1, np.uint32),
         )
         bufs = Buffers(**{k: a.ptr(v) for k, v in self.tensors.items()})
         self._check(self.f['bind_buffers'](self._h, ctypes.byref(bufs)), 'bind_buffers')

@@ -66,8 +66,6 @@ def test_state_arrays_are_consistent():
     hot = t['hot']
     N = ctx.total_people
     state = hot & 7
-    bits = np.unpackbits(t['sus_bits'].view(np.uint8), bitorder='little')[:N]
-    assert np.array_equal(bits.astype(bool), state == 0)          # bitmap == "never infected"
     counters = ctx.per_age_counters()
     age_of = np.repeat(np.arange(ctx.nr_ages), ctx.age_counts)
     for name, st in (('susceptible', [0]), ('infected', [1, 2, 3, 4]), ('recovered', [5]), ('dead', [6])):

@@ -159,7 +159,8 @@ def test_conservation_at_scale(total):
     ctx = simulation.make_context(v, age_counts=ages, seed=1)
     hist = ctx.run(365)
     peak = int(ctx.engine.alloc.to_host(ctx.engine.tensors['control'])[eng.L_HOSP_PEAK])
-    assert (peak > 3 * 16384) if total > 100_000_000 else (peak == 0) if total < 100_000_000 else True, peak
+    # (the busiest day on which a bed or ICU unit could run out, i.e. whose events were walked in priority order)
+    assert peak > (3 * 16384 if total > 100_000_000 else 2000), peak
     del ctx
     A = eng.MAX_AGES
     N = int(ages.sum())

@@ -1,0 +1,9 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
+F="--offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fast-math"
+/opt/rocm/bin/hipcc $F -DREINA_HOSP_STAMPS -o /tmp/libreina_hs.so reina_model_amd/csrc/reina_hip.hip 2>/dev/null
+/opt/rocm/bin/hipcc $F -DREINA_INSTALL_STAMPS -o /tmp/libreina_is.so reina_model_amd/csrc/reina_hip.hip 2>/dev/null
+for n in 1e8; do
+REINA_HIP_LIB=/tmp/libreina_hs.so python tools/stamps_peak.py $n hosp 2>&1 | tee $OUT/stamps_hosp_$n.txt
+REINA_HIP_LIB=/tmp/libreina_is.so python tools/stamps_peak.py $n inst 2>&1 | tee $OUT/stamps_inst_$n.txt
+done
