@@ -216,7 +216,7 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
     uint32_t dl = clamp_days(e, rp_round_to_int(g));
     uint32_t nw = RS_INCUBATION | ((uint32_t)sev << 3) | (variant << 8) | (pod ? RH_POD_OUTSIDE : 0) |
                   (fresh ? RH_FRESH : 0) | (w & RH_VACCINATED) |
-                  (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0) |
+                  (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0) | RH_ACTIVE |
                   /* (a FRESH agent of the initial condition sits out the scan of day 0 first) */
                   RH_DAYS_FIELD(dl, (fresh && day == RP_INIT_DAY) ? day + 1u : day);
     e->buf.hot[t] = nw;
@@ -494,7 +494,7 @@ static void run_scan(Par *e, const reina_day_t *dp) {
             if (!(w & RH_INCLUDED)) {
                 SC(e, REINA_S_TOTAL_INFECTORS) += 1;
                 SC(e, REINA_S_TOTAL_INFECTIONS) += e->buf.n_infected[i];
-                e->buf.hot[i] = w | RH_INCLUDED;
+                e->buf.hot[i] = (w | RH_INCLUDED) & ~RH_ACTIVE;
             }
             continue;
         }

@@ -215,6 +215,8 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 //  bit   12   fresh: infected before today's scan (day_of_infection == today, main.pyx:402)
 //  bit   13   vaccinated (day_of_vaccination >= 0)
 //  bit   14   has infectee list (infected while contact tracing was on, main.pyx:227-233)
+//  bit   15   active: needs the day's state machine (infected, or removed but not yet counted into R): set when
+//             the agent is infected, cleared when its removal has been counted -- the streaming pass tests this bit only
 //  bits 16-23 days_left, as the absolute day (mod 256) whose scan finds it at 0 (see RH_DAYS_LEFT below)
 //  bits 24-31 day_of_illness, as the absolute day (mod 256) whose scan finds it at 0
 #define RH_STATE(w) ((w) & 7u)
@@ -227,6 +229,7 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 #define RH_FRESH 0x1000u
 #define RH_VACCINATED 0x2000u
 #define RH_HASLIST 0x4000u
+#define RH_ACTIVE 0x8000u
 #define RH_SET_STATE(w, s) (((w) & ~7u) | (uint32_t)(s))
 // days_left / day_of_illness are kept as ABSOLUTE days (mod 256), so the word of an agent that is only
 // waiting does not change from one day to the next (no daily write-back): bits 16-23 = the day whose
