@@ -38,11 +38,14 @@ extern "C" {
                                    cleared (the reference's default scenario runs 565 days, variables.py:233) */
 #define REINA_PRESSURE_WORDS (REINA_MAX_SHARDS * REINA_MAX_RANGES * REINA_MAX_VARIANTS)
 #define REINA_MIRROR_CELLS (REINA_MAX_RANGES * REINA_MAX_VARIANTS)
-/* sharded populations: the pressure words of contact range REINA_MAX_RANGES - 1 (never a real range: a
- * sharded engine accepts at most REINA_MAX_RANGES - 1) carry each shard's free beds / free ICU units
- * through the same all-reduce, from which the free capacity is re-divided every evening */
+/* sharded populations: the four pressure words of contact range REINA_MAX_RANGES - 1 (never a real range: a
+ * sharded engine accepts at most REINA_MAX_RANGES - 1) carry each shard's free beds / free ICU units at day open and
+ * its demand of the day (admission / ICU-transfer requests) through the same all-reduce; every shard then takes its
+ * demand-proportional share of the pooled free capacity before it walks its bed / ICU events (rp_capacity_share) */
 #define REINA_PRESSURE_FREE_BEDS(rank) (((rank) * REINA_MAX_RANGES + (REINA_MAX_RANGES - 1)) * REINA_MAX_VARIANTS)
 #define REINA_PRESSURE_FREE_ICU(rank) (REINA_PRESSURE_FREE_BEDS(rank) + 1)
+#define REINA_PRESSURE_DEMAND_BEDS(rank) (REINA_PRESSURE_FREE_BEDS(rank) + 2)
+#define REINA_PRESSURE_DEMAND_ICU(rank) (REINA_PRESSURE_FREE_BEDS(rank) + 3)
 
 /* error codes */
 #define REINA_OK 0
@@ -301,9 +304,10 @@ typedef int (*reina_allreduce_fn)(const void *sendbuff, void *recvbuff, size_t c
                                   void *comm, void *stream);
 int reina_set_collective(reina_engine_t *e, reina_allreduce_fn allreduce, void *comm);
 /* the same day in two halves for a sharded population: `begin` runs everything up to and including
- * contact sampling and leaves this shard's outgoing pressure in buffers.pressure; the caller sums
- * `pressure` over all shards (ncclAllReduce / torch.distributed.all_reduce, the ONLY per-day
- * collective); `end` realises the pressure aimed at this shard and installs the day's infections.
+ * contact sampling and leaves this shard's outgoing pressure (and its free capacity / demand words) in
+ * buffers.pressure; the caller sums `pressure` over all shards (ncclAllReduce / torch.distributed.all_reduce,
+ * the ONLY per-day collective); `end` takes this shard's share of the pooled beds / ICU units, realises the
+ * pressure aimed at this shard, walks the bed / ICU events and installs the day's infections.
  * reina_step_day == begin + end (with n_shards == 1 nothing is exchanged). */
 int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream);
 int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream);

@@ -592,10 +592,6 @@ static void run_hospital_events(Par *e, const reina_day_t *dp);
 
 static void run_hospital(Par *e, const reina_day_t *dp) {
     run_hospital_events(e, dp);
-    if (e->cfg.n_shards > 1) {   /* this shard's free capacity travels with the pressure all-reduce */
-        e->buf.pressure[REINA_PRESSURE_FREE_BEDS(e->cfg.shard_rank)] = SC(e, REINA_S_AVAILABLE_BEDS);
-        e->buf.pressure[REINA_PRESSURE_FREE_ICU(e->cfg.shard_rank)] = SC(e, REINA_S_AVAILABLE_ICU);
-    }
 }
 
 static void run_hospital_events(Par *e, const reina_day_t *dp) {
@@ -923,7 +919,7 @@ static void run_remote(Par *e, const reina_day_t *dp) {
                 uint32_t *cd = e->buf.candidates + 4u * (uint32_t)CTL(e, REINA_L_CAND)++;
                 cd[0] = t;
                 cd[1] = src;
-                /* a local stand-in source: its word as it stands now (after the day's bed / ICU walk) */
+                /* a local stand-in source: its word as it stands now (before the day's bed / ICU walk) */
                 cd[2] = v | ((!(src & RP_REMOTE_SRC) && (e->buf.hot[src] & RH_HASLIST)) ? 0x100u : 0u);
                 cd[3] = prio;
             }
@@ -938,18 +934,6 @@ static void run_install(Par *e, const reina_day_t *dp) {
         if (RH_STATE(e->buf.hot[cd[0]]) != RS_SUSCEPTIBLE) continue; /* duplicate record of the winner */
         int32_t src = (cd[1] & RP_REMOTE_SRC) ? -1 : (int32_t)cd[1];
         install_infection(e, cd[0], dp->day, cd[2] & 0xFFu, src, 0, dp->testing_mode, (cd[2] >> 8) & 1u);
-    }
-    /* the free beds / ICU units of all shards are pooled and re-divided for tomorrow (a shard whose share
-     * is exhausted gets part of what the others have free; totals are conserved) */
-    if (e->cfg.n_shards > 1) {
-        int64_t fb = 0, fc = 0;
-        for (uint32_t r = 0; r < e->cfg.n_shards; r++) {
-            fb += e->buf.pressure[REINA_PRESSURE_FREE_BEDS(r)];
-            fc += e->buf.pressure[REINA_PRESSURE_FREE_ICU(r)];
-        }
-        const int64_t G = e->cfg.n_shards, rk = e->cfg.shard_rank;
-        if (fb >= 0) SC(e, REINA_S_AVAILABLE_BEDS) = (int32_t)(fb / G + (rk < fb % G ? 1 : 0));
-        if (fc >= 0) SC(e, REINA_S_AVAILABLE_ICU) = (int32_t)(fc / G + (rk < fc % G ? 1 : 0));
     }
     /* tomorrow's mirror-table sizes: about twice this shard's share of today's cross-shard attempts of
      * the cell (pressure holds the sums over all shards by now), a power of two in [8, mirror_slots] */
@@ -1000,16 +984,31 @@ int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
     run_imports(e, dp, 0, &import_base);
     run_testing(e, dp);
     run_vaccinations(e, dp);
+    /* a sharded population's free capacity at day open and (below) its demand travel with the pressure all-reduce */
+    const int32_t free_beds_open = SC(e, REINA_S_AVAILABLE_BEDS), free_icu_open = SC(e, REINA_S_AVAILABLE_ICU);
     run_scan(e, dp);
-    run_hospital(e, dp);
     run_contacts(e, dp);
+    if (e->cfg.n_shards > 1) {
+        e->buf.pressure[REINA_PRESSURE_FREE_BEDS(e->cfg.shard_rank)] = free_beds_open;
+        e->buf.pressure[REINA_PRESSURE_FREE_ICU(e->cfg.shard_rank)] = free_icu_open;
+        e->buf.pressure[REINA_PRESSURE_DEMAND_BEDS(e->cfg.shard_rank)] = CTL(e, REINA_L_HOSP_ADMIT);
+        e->buf.pressure[REINA_PRESSURE_DEMAND_ICU(e->cfg.shard_rank)] = CTL(e, REINA_L_ICU_ADMIT);
+    }
     return 0;
 }
 
 /* second half: after the caller has summed `pressure` over the shards */
 int par_step_day_end(Par *e, const reina_day_t *dp, void *stream) {
     (void)stream;
-    run_remote(e, dp);
+    if (e->cfg.n_shards > 1) {
+        /* this shard's share of the pooled free beds / ICU units, in proportion to today's demand */
+        SC(e, REINA_S_AVAILABLE_BEDS) = rp_capacity_share(e->buf.pressure, e->cfg.n_shards, e->cfg.shard_rank, REINA_PRESSURE_FREE_BEDS(0),
+                                                          REINA_MAX_RANGES * REINA_MAX_VARIANTS, 0, 2);
+        SC(e, REINA_S_AVAILABLE_ICU) = rp_capacity_share(e->buf.pressure, e->cfg.n_shards, e->cfg.shard_rank, REINA_PRESSURE_FREE_BEDS(0),
+                                                         REINA_MAX_RANGES * REINA_MAX_VARIANTS, 1, 3);
+    }
+    run_remote(e, dp);     /* (a stand-in source's infectee-list flag: its word before the day's bed / ICU walk) */
+    run_hospital(e, dp);
     run_install(e, dp);
     return 0;
 }

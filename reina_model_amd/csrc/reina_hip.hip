@@ -467,13 +467,6 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         LAUNCH_TIMED(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, e->cfg.n_shards), s,
                      refs, dp, lds_rows);
     }
-    if (e->cfg.n_shards > 1) {  // the bed / ICU events before the all-reduce, which carries the shards' free capacity
-        const int hg = grid_for(N / 4096 + 1, HOSP_THREADS, 64);
-        const bool par = e->h_params.hosp_parallel != 0;
-        LAUNCH_TIMED(e, today, REINA_PK_HOSPITAL, k_hosp_install, dim3(hg, K), dim3(HOSP_THREADS), par ? 0 : (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
-                     refs, dp, scan_waves, scan_tiles, par ? HI_EVENTS : (HI_HOSP_WG | HI_EVENTS));
-        if (par) launch_parallel_walk(e, refs, K, dp, today, s);
-    }
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
@@ -482,7 +475,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
     const uint32_t N = e->cfg.n_agents;
     const int today = profiled_kind(e, dp.day);
     const bool sharded = e->cfg.n_shards > 1;
-    if (sharded)
+    if (sharded)   // (also takes this shard's share of the pooled free beds / ICU units: the walk below starts from it)
         LAUNCH_TIMED(e, today, REINA_PK_REMOTE, k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
@@ -491,9 +484,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         // (groups: 128 workgroups for all members together -- every workgroup pays its prologue and its histogram flush)
         if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 2;
         const bool par = e->h_params.hosp_parallel != 0;
-        if (sharded) {
-            LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig, K), dim3(HOSP_THREADS), 0, s, refs, dp, scan_waves, scan_tiles, HI_INSTALL);
-        } else if (par) {
+        if (par) {
             // a large population: the events of a day on which order matters are walked by one workgroup per bucket
             LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig, K), dim3(HOSP_THREADS), 0, s, refs, dp, scan_waves, scan_tiles,
                          HI_INSTALL | HI_EVENTS);

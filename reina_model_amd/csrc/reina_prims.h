@@ -266,6 +266,32 @@ RP_HD uint32_t rp_priority20(uint32_t k0, uint32_t k1, uint32_t who, uint32_t da
 RP_HD uint64_t rp_shard_seed(uint64_t seed, uint32_t rank) {
     return seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;
 }
+// Sharded populations: the free beds (ICU units) of ALL shards at day open are re-divided every day in proportion to
+// the day's demand (admission / transfer requests), so that capacity goes where the patients are: a shard's share of
+// T = sum of free units is floor(T * d[rank] / D), the first T - sum(floors) shards with demand get one more.
+// `words` = the all-reduced pressure block; shard s keeps its free count at words[first + s * stride + k_free] and
+// its demand at [... + k_dem].  No demand anywhere (or a negative pool): everyone keeps what it has.
+RP_HD int32_t rp_capacity_share(const int32_t *words, uint32_t n_shards, uint32_t rank, uint32_t first, uint32_t stride,
+                                uint32_t k_free, uint32_t k_dem) {
+    int64_t T = 0, D = 0;
+    for (uint32_t s = 0; s < n_shards; s++) {
+        T += words[first + s * stride + k_free];
+        D += words[first + s * stride + k_dem];
+    }
+    const int32_t own = words[first + rank * stride + k_free];
+    if (D <= 0 || T < 0) return own;
+    int64_t given = 0;
+    for (uint32_t s = 0; s < n_shards; s++) given += T * words[first + s * stride + k_dem] / D;
+    int64_t extra = T - given;   // < number of shards with demand
+    int64_t mine = T * words[first + rank * stride + k_dem] / D;
+    for (uint32_t s = 0; s <= rank && extra > 0; s++)
+        if (words[first + s * stride + k_dem] > 0) {
+            if (s == rank) mine += 1;
+            extra--;
+        }
+    return (int32_t)mine;
+}
+
 // candidate "source id" of an infection realised from cross-shard pressure (no local infector)
 #define RP_REMOTE_SRC 0x80000000u
 #define RP_MIRROR_PROBES 16u      // probes per cell of the mirror table (tables are kept >= ~40 % full)

@@ -108,6 +108,31 @@ def run_parallel_ensemble(family, seeds, engine_factory=None, device='cuda:0', g
     return out, meta
 
 
+def run_sharded_ensemble(family, seeds, G, engine_factory=None, device='cuda:0'):
+    """the family's scenario with the population split over G shards stepped in lock-step in ONE process (the
+    per-day pressure exchange emulated on the host, reina_model_amd.sharding.step_shards_together); the global
+    history is the sum over the shards.  Returns (series dict, meta)."""
+    from reina_model_amd import engine as eng, sharding, simulation
+    z, meta = load_ref(family)
+    v = variables_for(meta)
+    ages = np.asarray(meta['age_counts'])
+    D = meta['days']
+    hist = np.zeros((len(list(seeds)), D, eng.COUNTER_WORDS), dtype=np.int64)
+    ctxs = None
+    for k, seed in enumerate(seeds):
+        members = []
+        ctxs = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=meta['interventions'], ipc=meta.get('ipc'),
+                                        engine_factory=engine_factory, device=device, comm=sharding.InProcessComm(r, G, members))
+                for r in range(G)]
+        mob = []
+        for d in range(D):
+            hist[k, d] = sharding.reduce_counters(ctxs)
+            mob.append(float(ctxs[0].contact_matrix.mobility_factor))
+            sharding.step_shards_together(ctxs)
+        ctxs[0].mobility_history = mob
+    return series_from_history(hist, meta, ctxs[0]), meta
+
+
 def _welch(name, g, r, out, min_mean=MIN_MEAN):
     """g, r: per-run samples of one quantity -> appends (name, z, mean_ref, mean_par, tol_rel)"""
     g = np.asarray(g, dtype=np.float64)

@@ -18,6 +18,10 @@ def work(args):
     family, seeds, patch = args
     import par_backend
     import ref_stats
+    G = int(os.environ.get('REF_COMPARE_SHARDS', '0'))
+    if G:
+        par, _ = ref_stats.run_sharded_ensemble(family, seeds, G, engine_factory=par_backend.par_engine_factory)
+        return par
     par, _ = ref_stats.run_parallel_ensemble(family, seeds, engine_factory=par_backend.par_engine_factory, group=len(seeds),
                                              variables_patch=patch)
     return par
@@ -33,7 +37,7 @@ def main():
     import ref_stats
     seeds = list(range(60000, 60000 + n))
     chunks = [seeds[i::jobs] for i in range(jobs) if seeds[i::jobs]]
-    cache = '/tmp/ref_compare_%s_%d_%s.npz' % (family, n, '_'.join('%s%g' % kv for kv in sorted(patch.items())))
+    cache = '/tmp/ref_compare_%s_%d_%s_g%s.npz' % (family, n, '_'.join('%s%g' % kv for kv in sorted(patch.items())), os.environ.get('REF_COMPARE_SHARDS', '0'))
     if os.path.exists(cache):
         par = dict(np.load(cache))
     else:
