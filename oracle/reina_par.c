@@ -215,10 +215,11 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
     float g = rp_gamma_mu_cv(e->dis.mean_incubation_duration[0], 0.86f, e->k0, e->k1, t, day, RP_P_INFECT, 1);
     uint32_t dl = clamp_days(e, rp_round_to_int(g));
     uint32_t nw = RS_INCUBATION | ((uint32_t)sev << 3) | (variant << 8) | (pod ? RH_POD_OUTSIDE : 0) |
-                  (fresh ? RH_FRESH : 0) | (w & RH_VACCINATED) |
+                  (w & RH_VACCINATED) |
                   (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0) | RH_ACTIVE |
                   /* (a FRESH agent of the initial condition sits out the scan of day 0 first) */
-                  RH_DAYS_FIELD(dl, (fresh && day == RP_INIT_DAY) ? day + 1u : day);
+                  RH_DAYS_FIELD(dl, (fresh && day == RP_INIT_DAY) ? day + 1u : day) |
+                  RH_INFECTED_ON((fresh && day == RP_INIT_DAY) ? day + 1u : day);
     e->buf.hot[t] = nw;
     if (src >= 0) {
         e->buf.infector[t] = src;
@@ -498,8 +499,7 @@ static void run_scan(Par *e, const reina_day_t *dp) {
             }
             continue;
         }
-        if (st == RS_INCUBATION && (w & RH_FRESH)) {
-            e->buf.hot[i] = w & ~RH_FRESH;
+        if (RH_INFECTED_TODAY(w, dp->day)) {   /* infected earlier today (an import): waits, main.pyx:402 */
             continue;
         }
         int age = age_of(e, i);

@@ -278,6 +278,7 @@ int reina_bind_buffers(reina_engine_t *e, const reina_buffers_t *b) {
     r.T = e->d_tables;
     r.B = e->buf;
     r.history_base = nullptr;
+
     HIP_CHECK(hipMemcpy(e->d_ref, &r, sizeof(MemberRef), hipMemcpyHostToDevice));
     return REINA_OK;
 }
@@ -440,33 +441,35 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     for (uint32_t b = 0; b < dp.n_import_batches; b++)
         (dp.import_batches[b].pre_init ? n_pre : n_post) += dp.import_batches[b].count;
     const int weekly_own = n_pre == 0 && n_post > 0;   // (intervention imports share the claim keys: same workgroup then)
-    if (!e->testing_ever) {
-        LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open<0>, dim3(2, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
-    } else {
-        // (groups: the members share the chip, so each gets proportionally fewer workgroups per phase)
-        int tg = grid_for(N / 64 + 1, PRO_THREADS, 64);
-        if (K > 1 && tg > (int)(e->n_cus / K)) tg = e->n_cus / K > 0 ? (int)(e->n_cus / K) : 1;
-        const int g = 2 + tg;
-        if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT && N <= 8000000u) {
-            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open<3>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces, both levels
-        } else if (dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open<2>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);  // detects + traces level 0
-            LAUNCH_TIMED(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
-        } else {
-            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open<1>, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own);
-        }
-    }
-    if (dp.n_vaccinations) LAUNCH_TIMED(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
-    // the stream: tiles of 512 agents, as many waves as tiles (small populations) up to 16 per CU
+    // the day's opening: roles (0 opens the day, 1 weekly imports, 2.. the test queue) by arrival ticket
+    // (groups: the members share the chip, so each gets proportionally fewer workgroups per phase)
+    int tg = grid_for(N / 64 + 1, PRO_THREADS, 64);
+    if (K > 1 && tg > (int)(e->n_cus / K)) tg = e->n_cus / K > 0 ? (int)(e->n_cus / K) : 1;
+    const bool ct = dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
     const uint32_t day_blocks = day_blocks_for(N, K, e->n_cus);
-    const uint32_t scan_waves = day_blocks * DAY_WAVES;
+    uint32_t lds_rows = K > 1 ? e->group_lds_rows : e->h_tables.n_rows;   // (a member stages min(its own rows, lds_rows))
+    if (lds_rows > REINA_LDS_ROWS) lds_rows = REINA_LDS_ROWS;
     {
-        uint32_t lds_rows = K > 1 ? e->group_lds_rows : e->h_tables.n_rows;   // (a member stages min(its own rows, lds_rows))
-        if (lds_rows > REINA_LDS_ROWS) lds_rows = REINA_LDS_ROWS;
+        const int g = 2 + tg;
+        if (!e->testing_ever) {
+            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open, dim3(2, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own, 0);
+        } else if (ct && N <= 8000000u) {
+            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own, 3);  // detects + traces, both levels
+        } else if (ct) {
+            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own, 2);  // detects + traces level 0
+            LAUNCH_TIMED(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
+        } else {
+            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own, 1);
+        }
+        // a vaccination programme: its pass over the agents comes after the test queue and before the stream
+        // (HealthcareSystem.iterate, main.pyx:514-558)
+        if (dp.n_vaccinations) LAUNCH_TIMED(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
         LAUNCH_TIMED(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, e->cfg.n_shards), s,
                      refs, dp, lds_rows);
     }
+    e->cur_scan_waves = day_blocks * DAY_WAVES;   // (the day's later launches walk the per-wave slices)
+    (void)scan_tiles;
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
@@ -479,7 +482,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         LAUNCH_TIMED(e, today, REINA_PK_REMOTE, k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-        const uint32_t scan_waves = day_blocks_for(N, K, e->n_cus) * DAY_WAVES;
+        const uint32_t scan_waves = e->cur_scan_waves;
         int ig = grid_for(N / 64 + 1, HOSP_THREADS, 128) * 2;  // even: candidates / deferred lists
         // (groups: 128 workgroups for all members together -- every workgroup pays its prologue and its histogram flush)
         if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 2;
@@ -577,6 +580,7 @@ int reina_group_create(reina_engine_t **engines, uint32_t n, reina_group_t **out
         g->h_refs[k].T = engines[k]->d_tables;
         g->h_refs[k].B = engines[k]->buf;
         g->h_refs[k].history_base = nullptr;
+
     }
     HIP_CHECK_OR(hipMalloc(&g->d_refs, sizeof(MemberRef) * n), delete g);
     HIP_CHECK_OR(hipMemcpy(g->d_refs, g->h_refs.data(), sizeof(MemberRef) * n, hipMemcpyHostToDevice),   // (table broadcasts may precede the first run)
@@ -658,7 +662,10 @@ int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_d
         rc = launch_day_end(e0, g->d_refs, K, dp, s);
         if (rc) return rc;
     }
-    for (auto m : g->members) m->testing_ever = m->testing_ever || e0->testing_ever;
+    for (auto m : g->members) {
+        m->testing_ever = m->testing_ever || e0->testing_ever;
+        m->cur_scan_waves = e0->cur_scan_waves;
+    }
     return REINA_OK;
 }
 

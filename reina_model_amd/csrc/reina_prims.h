@@ -212,13 +212,15 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 //  bits  8-9  variant_idx
 //  bit   10   included_in_totals
 //  bit   11   place_of_death == DEATH_OUTSIDE_HOSPITAL
-//  bit   12   fresh: infected before today's scan (day_of_infection == today, main.pyx:402)
+//  bit   12   (free)
 //  bit   13   vaccinated (day_of_vaccination >= 0)
 //  bit   14   has infectee list (infected while contact tracing was on, main.pyx:227-233)
 //  bit   15   active: needs the day's state machine (infected, or removed but not yet counted into R): set when
 //             the agent is infected, cleared when its removal has been counted -- the streaming pass tests this bit only
 //  bits 16-23 days_left, as the absolute day (mod 256) whose scan finds it at 0 (see RH_DAYS_LEFT below)
-//  bits 24-31 day_of_illness, as the absolute day (mod 256) whose scan finds it at 0
+//  bits 24-31 ILLNESS and later: day_of_illness, as the absolute day (mod 256) whose scan finds it at 0;
+//             INCUBATION: the day of infection (mod 256) -- an agent infected before today's scan (an import) sits that
+//             scan out (day_of_infection == today, main.pyx:402): the scan compares this field with today
 #define RH_STATE(w) ((w) & 7u)
 #define RH_SEV(w) (((w) >> 3) & 7u)
 #define RH_DETECTED 0x40u
@@ -226,7 +228,6 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 #define RH_VARIANT(w) (((w) >> 8) & 3u)
 #define RH_INCLUDED 0x400u
 #define RH_POD_OUTSIDE 0x800u
-#define RH_FRESH 0x1000u
 #define RH_VACCINATED 0x2000u
 #define RH_HASLIST 0x4000u
 #define RH_ACTIVE 0x8000u
@@ -246,6 +247,10 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 #define RH_DAYS_FIELD(d, day) ((((uint32_t)(day) + 1u + (uint32_t)(d)) & 0xFFu) << 16)
 #define RH_SET_DAYS_LEFT(w, d, day) (((w) & ~0x00FF0000u) | RH_DAYS_FIELD(d, day))
 #define RH_SET_DOI0(w, day) (((w) & 0x00FFFFFFu) | ((((uint32_t)(day) + 1u) & 0xFFu) << 24))
+// INCUBATION: infected on `day` (an agent of the initial condition that stays incubating: counted as infected on day 0,
+// whose scan it sits out)
+#define RH_INFECTED_ON(day) (((uint32_t)(day) & 0xFFu) << 24)
+#define RH_INFECTED_TODAY(w, day) (RH_STATE(w) == RS_INCUBATION && ((w) >> 24) == ((uint32_t)(day) & 0xFFu))
 
 enum { RS_SUSCEPTIBLE = 0, RS_INCUBATION, RS_ILLNESS, RS_HOSPITALIZED, RS_IN_ICU, RS_RECOVERED, RS_DEAD };
 enum { RV_ASYMPTOMATIC = 0, RV_MILD, RV_SEVERE, RV_CRITICAL, RV_FATAL };
