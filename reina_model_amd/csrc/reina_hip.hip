@@ -144,7 +144,7 @@ static void free_engine(reina_engine *e) {
 
 extern "C" {
 
-int reina_abi_version(void) { return 1; }
+int reina_abi_version(void) { return 2; }
 
 int reina_build_contact_tables(const double *base, const int32_t *row_page, const int32_t *row_place, uint32_t n_rows,
                                const double *mobility, uint32_t n_mobility, const int32_t *rows_mat,

@@ -45,6 +45,7 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 48
 L_HOSP_PEAK = 12   # control word: event count of the busiest day that needed several priority ranges
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
+ABI_VERSION = 2   # reina_abi_version(): struct layouts of include/reina_hip.h (round 2: no sus_bits, bucketed hosp_events, 48 control words)
 PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install')
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
@@ -173,6 +174,10 @@ def bind_abi(lib, prefix):
     for name in ABI_FUNCTIONS:
         if name != 'last_error':
             f[name].restype = ctypes.c_int
+    got = f['abi_version']()
+    if got != ABI_VERSION:
+        raise EngineError('%sabi_version() = %d, this binding is written for %d (stale library? run python -m reina_model_amd.build)'
+                          % (prefix, got, ABI_VERSION))
     return f
 
 
