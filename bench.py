@@ -26,7 +26,7 @@ Objects on the line:
                  HIP events on the launch stream inside the timed region (one kind of kernel per profiled
                  day, the kinds taking turns), its share of the day, and -- where the kernel has
                  algorithmic bytes of its own -- bytes per launch and achieved GB/s.  `dominant_kernel`
-                 names the streaming kernel k_scan with its per-launch figure.  `traffic`: HBM bytes per
+                 names the streaming kernel k_day with its per-launch figure.  `traffic`: HBM bytes per
                  day from PMC counters (profiles/traffic.json: separate rocprofv3 --pmc passes, FETCH_SIZE
                  doubled per MI355X_MICROARCH.md); only reported when that file was collected on the very
                  library binary being timed (sha256 match), else null.
@@ -451,7 +451,7 @@ def main():
     res = run_gpu(v, ages, a.seed, a.steps, a.warmup, device, dist, preheat=a.preheat_days, stride=stride)
     res['dt'] = max_over_ranks(res['dt'])
     total_agents = int(np.asarray(ages).sum())
-    n_agents = total_agents // world   # agents one k_scan launch streams on this rank
+    n_agents = total_agents // world   # agents one k_day launch streams on this rank
     value = total_agents * a.steps / res['dt']
 
     large_sharded = None

@@ -131,7 +131,7 @@ typedef struct {
                                  sizes the event buckets; more than REINA_HOSP_BUCKET_CAP keys in one bucket, or more
                                  than one workgroup's walk holds in a small population, fail the run (problem 103) */
     uint64_t seed;            /* Philox key (random_seed of Context, main.pyx:1759); same on all shards,
-                                 the engine mixes the rank in */            /* Philox key (random_seed of Context, main.pyx:1759) */
+                                 the engine mixes the rank in */
     uint32_t max_work_items;  /* capacity of work_items (records) */
     uint32_t max_candidates;  /* capacity of candidates (records) */
     uint32_t max_queue;       /* capacity of each testing queue */

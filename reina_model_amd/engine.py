@@ -43,7 +43,7 @@ S_INFECTED_BY_VARIANT = 24
 S_NR = 32
 COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 48
-L_HOSP_PEAK = 12   # control word: event count of the busiest day that needed several priority ranges
+L_HOSP_PEAK = 12   # control word: bed / ICU event count of the busiest day on which the events' order mattered
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
 ABI_VERSION = 2   # reina_abi_version(): struct layouts of include/reina_hip.h (round 2: no sus_bits, bucketed hosp_events, 48 control words)
 PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install')

@@ -505,9 +505,9 @@ def test_more_bed_events_in_a_day_than_one_pass_holds():
 
 
 def test_large_engine_group_geometry():
-    """64 members: each gets 3 contact workgroups, 8 k_install workgroups and a slice count rounded to a
-    multiple of its contact waves (reina_hip.hip: scan_blocks_for / con_blocks_for), tables arrive by
-    broadcast -- sampled members == oracle B run alone, bit for bit."""
+    """64 members: each gets n_cus / 64 = 4 k_day workgroups and its share of the k_hosp_install workgroups
+    (reina_hip.hip: day_blocks_for), tables arrive by broadcast -- sampled members == oracle B run alone, bit
+    for bit."""
     import par_backend
     from reina_model_amd import ensemble
     v = copy.deepcopy(VARIABLE_DEFAULTS)

@@ -27,3 +27,6 @@ for k, v in b.get('full_scenario', {}).items():
 e=b.get('ensemble', {})
 print('ensemble', e.get('value'), e.get('ms_per_step'), e.get('kernels'), e.get('error'))
 PY
+# the N > 1 plumbing on a 1-GPU box: bench.py launches its own two ranks (gloo, both on cuda:0) -- not a measurement
+REINA_BENCH_BACKEND=gloo REINA_BENCH_ONE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-large --no-ensemble --no-cpu --no-sizes > $OUT/${TAG}_bench2.json 2> $OUT/${TAG}_bench2.err
+echo "two-rank hook rc=$?"; head -c 400 $OUT/${TAG}_bench2.json; echo

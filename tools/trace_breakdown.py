@@ -1,5 +1,5 @@
 """Per-kernel duration distribution and inter-kernel gaps over the timed region (the last `days`
-k_scan launches) of a rocprofv3 kernel trace.  usage: trace_breakdown.py <kernel_trace.csv> [days]"""
+k_day launches) of a rocprofv3 kernel trace.  usage: trace_breakdown.py <kernel_trace.csv> [days]"""
 import collections
 import csv
 import sys
@@ -12,7 +12,7 @@ by = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name'].split('(')[0].replace('void ', '')
     by[n].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
-scan = sorted(by['k_scan'])[-days:]
+scan = sorted(by['k_day'])[-days:]
 t0 = scan[0][0] - 60000
 tot = 0
 allk = []
