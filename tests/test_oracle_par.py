@@ -271,3 +271,36 @@ def test_intervention_sweep_as_one_group():
     bad['interventions'] = [iv for iv in bad['interventions'] if iv[0] != 'test-with-contact-tracing']
     with pytest.raises(ValueError):
         ensemble.run_sweep([vs[0], bad], [1, 2], 150, age_counts=ages, engine_factory=par_backend.par_engine_factory)
+
+
+def test_ensembles_start_from_the_initial_population_condition():
+    """calc/simulation.py:152: every simulation -- the Monte-Carlo ones included (run_monte_carlo ->
+    simulate_monte_carlo -> simulate_individuals) -- starts from the area's case-file row of the start date.
+    A start date the file lists (2020-03-26: 2 dead, 13 in ICU, 42 in ward, 819 confirmed) plus unmeasured numbers
+    from the variables: every ensemble / sweep member equals the single run of the same seed, which differs from
+    a run without the condition."""
+    import copy
+    import numpy as np
+    import par_backend
+    from reina_model_amd import datasets, ensemble, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(start_date='2020-03-26', ill_at_simulation_start=60, incubating_at_simulation_start=90,
+             recovered_at_simulation_start=300, hospital_beds=60, icu_units=15)
+    v['interventions'] = [iv for iv in v['interventions'] if iv[1] >= '2020-03-26']
+    ipc = datasets.get_initial_population_condition(v)
+    assert (ipc.dead, ipc.in_icu, ipc.in_ward, ipc.confirmed_cases) == (2, 13, 42, 819)
+    ages = datasets.scaled_population(30000)
+    pf = par_backend.par_engine_factory
+    seeds = [11, 12]
+    singles = [simulation.make_context(v, age_counts=ages, seed=s, ipc=ipc, engine_factory=pf, device='cpu').run(25) for s in seeds]
+    bare = simulation.make_context(v, age_counts=ages, seed=seeds[0], ipc=None, engine_factory=pf, device='cpu').run(25)
+    assert not np.array_equal(singles[0], bare)
+    hist = ensemble.run_ensemble(v, seeds, 25, age_counts=ages, device='cpu', engine_factory=pf)      # ipc='auto'
+    for k in range(2):
+        assert np.array_equal(hist[k], singles[k]), k
+    hist2, _ = ensemble.run_sweep([v, v], seeds, 25, age_counts=ages, device='cpu', engine_factory=pf)
+    for k in range(2):
+        assert np.array_equal(hist2[k], singles[k]), k
+    none = ensemble.run_ensemble(v, seeds[:1], 25, age_counts=ages, device='cpu', engine_factory=pf, ipc=None)
+    assert np.array_equal(none[0], bare)
