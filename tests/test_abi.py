@@ -104,6 +104,8 @@ def test_kernels_fit_the_lds_they_ask_for():
     assert 'struct DayShared' in text
     assert day[0]['.group_segment_fixed_size:'] <= 3072     # (its big arrays are carved from the dynamic part: the
     #                                                          static_assert in k_contacts.inc leaves 3 KB for the rest)
+    # k_day addresses v104..v127 by hand (three tiles in flight, inline asm): the kernel descriptor must allocate them
+    assert day[0]['.vgpr_count:'] == 128, day[0]
     for k, v in kernels.items():
         # the streaming kernel must not touch scratch; the day's last launch (event walk + installs in one kernel) may
         # park a handful of registers
