@@ -618,11 +618,7 @@ static void run_hospital_events(Par *e, const reina_day_t *dp) {
                 w = dies_in_hospital(e, i, dp->day, sev, v, 0) ? do_die(e, w, age) : do_recover(e, w, age);
             } else {
                 b--;
-                float f;
-                if (sev == RV_SEVERE)
-                    f = od * (1.0f - d->ratio_of_duration_before_hospitalisation[v]);
-                else
-                    f = od * d->ratio_of_duration_in_ward[v];
+                const float f = rp_ward_stay(sev, od, d->ratio_of_duration_before_hospitalisation[v], d->ratio_of_duration_in_ward[v]);
                 w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)), dp->day);
                 CNT(e, REINA_C_HOSPITALIZED, age) += 1;
                 CNT(e, REINA_C_IN_WARD, age) += 1;
@@ -636,8 +632,7 @@ static void run_hospital_events(Par *e, const reina_day_t *dp) {
                 CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
                 w = do_die(e, w, age);
             } else {
-                float f = 1.0f - d->ratio_of_duration_in_ward[v] - d->ratio_of_duration_before_hospitalisation[v];
-                f *= od;
+                const float f = rp_icu_stay(sev, od, d->ratio_of_duration_before_hospitalisation[v], d->ratio_of_duration_in_ward[v]);
                 w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)), dp->day);
                 CNT(e, REINA_C_IN_WARD, age) -= 1;
                 CNT(e, REINA_C_IN_ICU, age) += 1;
@@ -739,8 +734,7 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
                     w = dies_in_hospital(e, t, RP_INIT_DAY, sev, v, 0) ? do_die(e, w, age) : do_recover(e, w, age);
                 } else if (!to_icu) {
                     b--;
-                    float f = sev == RV_SEVERE ? od * (1.0f - d->ratio_of_duration_before_hospitalisation[v])
-                                               : od * d->ratio_of_duration_in_ward[v];
+                    const float f = rp_ward_stay(sev, od, d->ratio_of_duration_before_hospitalisation[v], d->ratio_of_duration_in_ward[v]);
                     w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)), RP_INIT_DAY);
                     CNT(e, REINA_C_HOSPITALIZED, age) += 1;
                     CNT(e, REINA_C_IN_WARD, age) += 1;
@@ -750,8 +744,7 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
                     if (!unit && dies_in_hospital(e, t, RP_INIT_DAY, sev, v, 0)) {
                         w = do_die(e, w, age);   /* hospitalised and released at once: no net ward count */
                     } else {
-                        float f = 1.0f - d->ratio_of_duration_in_ward[v] - d->ratio_of_duration_before_hospitalisation[v];
-                        f *= od;
+                        const float f = rp_icu_stay(sev, od, d->ratio_of_duration_before_hospitalisation[v], d->ratio_of_duration_in_ward[v]);
                         w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)), RP_INIT_DAY);
                         CNT(e, REINA_C_HOSPITALIZED, age) += 1;
                         CNT(e, REINA_C_IN_ICU, age) += 1;
@@ -793,7 +786,12 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
         uint32_t prio = rp_priority20(e->k0, e->k1, src, dp->day);
         uint64_t key = rp_order_key(dp->day, prio, src);
         for (int c = 0; c < nr; c++) {
-            rp_u4 r = rp_philox(e->k0, e->k1, src, dp->day, RP_P_CONTACT, (uint32_t)c);
+            /* Philox2x32: half 0 = (place / age-range draw, transmission draw), half 1 = (shard + target draw, mask draw) */
+            const uint32_t ckey = rp_contact_key(e->k0, e->k1);
+            const rp_u2 q0 = rp_philox2(ckey, src, rp_contact_ctr(dp->day, (uint32_t)c, 0));
+            const rp_u2 q1 = rp_philox2(ckey, src, rp_contact_ctr(dp->day, (uint32_t)c, 1));
+            rp_u4 r;   /* (the names of the four draws as the formulation uses them) */
+            r.v[0] = q0.v[0]; r.v[2] = q0.v[1]; r.v[1] = q1.v[0]; r.v[3] = q1.v[1];
             int cnt = e->tcount[row];
             int ent = cnt - 1;
             for (int j = 0; j < cnt; j++)
@@ -1102,6 +1100,10 @@ const char *par_last_error(void) { return ""; }
 void par_test_philox(const uint32_t *key, const uint32_t *ctr, uint32_t *out) {
     rp_u4 r = rp_philox(key[0], key[1], ctr[0], ctr[1], ctr[2], ctr[3]);
     memcpy(out, r.v, 16);
+}
+void par_test_philox2(const uint32_t *key, const uint32_t *ctr, uint32_t *out) {
+    rp_u2 r = rp_philox2(key[0], ctr[0], ctr[1]);
+    memcpy(out, r.v, 8);
 }
 void par_test_expf(const float *x, float *y, int n) { for (int i = 0; i < n; i++) y[i] = rp_expf(x[i]); }
 void par_test_logf(const float *x, float *y, int n) { for (int i = 0; i < n; i++) y[i] = rp_logf(x[i]); }

@@ -60,11 +60,37 @@ RP_HD rp_u4 rp_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32
     return o;
 }
 
+// ------------------------------------------------------------------ Philox2x32-10
+// (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 philox2x32_R(10, ..):
+// 64-bit counter (c0, c1), one 32-bit key, one 32 x 32 -> 64 multiply per round instead of two.)  The contact draws
+// are nine tenths of all random numbers of a busy day and need two words each until a contact survives the thinning
+// (place / age range, transmission), two more after (target, mask): two words per block is their natural size.
+typedef struct { uint32_t v[2]; } rp_u2;
+#define RP_PHILOX2_M 0xD256D193u
+RP_HD rp_u2 rp_philox2(uint32_t key, uint32_t c0, uint32_t c1) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; r++) {
+        uint64_t p = (uint64_t)RP_PHILOX2_M * c0;
+        c0 = (uint32_t)(p >> 32) ^ key ^ c1;
+        c1 = (uint32_t)p;
+        key += RP_PHILOX_W0;
+    }
+    rp_u2 o;
+    o.v[0] = c0; o.v[1] = c1;
+    return o;
+}
+// contact draws of source `src` on `day`: key from the engine's Philox key, counter (src, day | contact # << 12 | half << 20);
+// half 0 -> (place / age-range draw, transmission draw), half 1 -> (shard + target draw, mask draw)
+RP_HD uint32_t rp_contact_key(uint32_t k0, uint32_t k1) { return k0 ^ (k1 * 0x9E3779B9u + 0x7F4A7C15u); }
+RP_HD uint32_t rp_contact_ctr(uint32_t day, uint32_t c, uint32_t half) { return (day & 0xFFFu) | (c << 12) | (half << 20); }
+
 // Purposes (counter word c2 low byte). The sub-index (contact number, import try, tracer id)
 // goes in c3 or the upper bits of c2; `who` (agent / event id) in c0, day in c1.
 enum {
     RP_P_NRCONTACTS = 1,  // (agent, day): v[0] normal for the lognormal contact count
-    RP_P_CONTACT = 2,     // (agent, day, c3 = contact #): place/range, target, infect, mask
+    RP_P_CONTACT = 2,     // (unused since the contact draws moved to Philox2x32: rp_contact_key / rp_contact_ctr)
     RP_P_INFECT = 3,      // (target, day, c3 = block): severity, incubation gamma
     RP_P_ONSET = 4,       // (agent, day, c3 = block): onset->removed gamma; block 0 v[3] = "tested anyway"
     RP_P_HOSPITAL = 5,    // (agent, day): no-bed / no-ICU death roll
@@ -254,6 +280,23 @@ RP_HD int rp_round_to_int(float f) { return (int)(f + 0.5f); }
 
 enum { RS_SUSCEPTIBLE = 0, RS_INCUBATION, RS_ILLNESS, RS_HOSPITALIZED, RS_IN_ICU, RS_RECOVERED, RS_DEAD };
 enum { RV_ASYMPTOMATIC = 0, RV_MILD, RV_SEVERE, RV_CRITICAL, RV_FATAL };
+// Disease.get_hospitalization_days / get_icu_days (main.pyx:1016-1039), before rounding: the ward / ICU stay of an agent
+// of severity `sev` whose onset-to-removal time is `od`.  ASYMPTOMATIC and MILD agents get 0 -- the day loop never
+// hospitalises them, but Population.set_initial_state (main.pyx:1452-1516) puts agents of ANY severity into ward and
+// ICU, and those leave again on the first day.
+RP_HD float rp_ward_stay(int sev, float od, float ratio_before_hospitalisation, float ratio_in_ward) {
+    if (sev == RV_SEVERE) return od * (1.0f - ratio_before_hospitalisation);
+    if (sev == RV_FATAL || sev == RV_CRITICAL) return od * ratio_in_ward;
+    return 0.0f;
+}
+RP_HD float rp_icu_stay(int sev, float od, float ratio_before_hospitalisation, float ratio_in_ward) {
+    if (sev == RV_FATAL || sev == RV_CRITICAL) {
+        float f = 1.0f - ratio_in_ward - ratio_before_hospitalisation;
+        f *= od;
+        return f;
+    }
+    return 0.0f;
+}
 enum { RT_NO_TESTING = 0, RT_ALL_WITH_SYMPTOMS_CT, RT_ALL_WITH_SYMPTOMS, RT_ONLY_SEVERE_SYMPTOMS };
 
 // "day" of every draw made while the initial population condition is applied (before day 0)

@@ -12,7 +12,7 @@ last one):
              generate_state() (free ICU units / beds, r, exposed_per_day, ct_cases_per_day, ...),
              daily_contacts by place and infected_by_variant:
                  |mean_par - mean_ref| <= Z_MAX * sqrt(var_par / n_par + var_ref / n_ref)
-             NO relative slack.  Cells whose pooled mean is below MIN_MEAN agents are skipped (a handful
+             NO relative slack.  Age-group cells whose pooled mean is below MIN_MEAN agents are skipped (a handful
              of events in hundreds of runs: no normal approximation) -- they are covered by their totals.
   variances  totals only: |log(var_par / var_ref)| <= Z_MAX * sqrt((k - 1) / n_par + (k - 1) / n_ref)
              with k the pooled sample kurtosis (the large-sample standard error of a log variance).
@@ -32,8 +32,12 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 Z_MAX = 4.5
-MIN_MEAN = 5.0
+MIN_MEAN = 5.0          # age-group cells
+MIN_MEAN_TOTAL = 1.0    # totals, scalars, places, variants: the mean of >= 128 runs of a count with mean >= 1 is in the
+#                         normal regime (e.g. in_icu of a 20 000-agent family: 2-5 agents, 6 units -- the old 4-run comparisons
+#                         were the only check of those until round 2)
 KS_P_MIN = 1e-3
+EARLY_DAYS = (1, 2, 3, 5, 7, 10)
 
 
 def load_ref(family):
@@ -154,9 +158,17 @@ def compare(par, ref, meta, z_max=Z_MAX):
     ck = [int(d) for d in ref['ck_days']]
     means, variances, ks = [], [], []
     ref_tot, ref_ck = ref['tot'].astype(np.float64), ref['ag_ck'].astype(np.float64)
+    # the first days in full: what Population.set_initial_state leaves behind decays within days (agents of any severity
+    # put into ward / ICU leave on day 1: the reference's get_hospitalization_days / get_icu_days give them 0 days), and
+    # the 15-day grid of the fixtures' age-group tables does not see it.  Totals only (the fixtures hold every day's totals).
+    for d in EARLY_DAYS:
+        if d in ck or d >= ref_tot.shape[1]:
+            continue
+        for i, n in enumerate(meta['pop13']):
+            _welch('day %d %s total' % (d, n), par['ag'][:, d, i].sum(axis=1), ref_tot[:, d, i], means, min_mean=MIN_MEAN_TOTAL)
     for ki, d in enumerate(ck):
         for i, n in enumerate(meta['pop13']):
-            _welch('day %d %s total' % (d, n), par['ag'][:, d, i].sum(axis=1), ref_tot[:, d, i], means)
+            _welch('day %d %s total' % (d, n), par['ag'][:, d, i].sum(axis=1), ref_tot[:, d, i], means, min_mean=MIN_MEAN_TOTAL)
             for gidx in range(ref_ck.shape[3]):
                 _welch('day %d %s group %d' % (d, n, gidx), par['ag'][:, d, i, gidx], ref_ck[:, ki, i, gidx], means)
         for i, n in enumerate(meta['scalars']):
@@ -166,11 +178,11 @@ def compare(par, ref, meta, z_max=Z_MAX):
                     means.append(('day %d %s' % (d, n), np.inf, float(ref['scal'][0, d, i]), float(par['scal'][0, d, i]), 0.0))
                 continue
             _welch('day %d %s' % (d, n), par['scal'][:, d, i], ref['scal'][:, d, i], means,
-                   min_mean=0.05 if n == 'r' else MIN_MEAN)
+                   min_mean=0.05 if n == 'r' else MIN_MEAN_TOTAL)
         for i, n in enumerate(meta['places']):
-            _welch('day %d daily_contacts %s' % (d, n), par['dc'][:, d, i], ref['dc'][:, d, i], means)
+            _welch('day %d daily_contacts %s' % (d, n), par['dc'][:, d, i], ref['dc'][:, d, i], means, min_mean=MIN_MEAN_TOTAL)
         for i, n in enumerate(meta['variant_names']):
-            _welch('day %d infected_by_variant %s' % (d, n), par['ibv'][:, d, i], ref['ibv'][:, d, i], means)
+            _welch('day %d infected_by_variant %s' % (d, n), par['ibv'][:, d, i], ref['ibv'][:, d, i], means, min_mean=MIN_MEAN_TOTAL)
         # variance ratios of the totals
         for i, n in enumerate(meta['pop13']):
             g, r = par['ag'][:, d, i].sum(axis=1).astype(np.float64), ref_tot[:, d, i]

@@ -40,6 +40,21 @@ def test_philox4x32_10_known_answers(L):
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
+def test_philox2x32_10_known_answers(L):
+    """Random123 kat_vectors, philox2x32 10: (ctr0 ctr1 key) -> (out0 out1)"""
+    L.par_test_philox2.argtypes = [vp, vp, vp]
+
+    def ph(key, ctr):
+        k = np.array([key], dtype=np.uint32)
+        c = np.array(ctr, dtype=np.uint32)
+        o = np.zeros(2, dtype=np.uint32)
+        L.par_test_philox2(k.ctypes.data, c.ctypes.data, o.ctypes.data)
+        return [int(x) for x in o]
+    assert ph(0, [0, 0]) == [0xff1dae59, 0x6cd10df2]
+    assert ph(0xffffffff, [0xffffffff, 0xffffffff]) == [0x2c3f628b, 0xab4fd7ad]
+    assert ph(0x13198a2e, [0x243f6a88, 0x85a308d3]) == [0xdd7ce038, 0xf62a4c12]
+
+
 def test_expf_logf_accuracy(L):
     x = np.linspace(-20, 20, 400001).astype(np.float32)
     y = np.zeros_like(x)
