@@ -237,7 +237,11 @@ typedef struct {
  * applies those BEFORE Population.init_day zeroes new_infections / infected_by_variant
  * (main.pyx:2013-2016 then :1687-1699), so they do not show up in those daily counters; weekly
  * imports (infect_people_daily, :1671-1685) run after the zeroing and do. */
-typedef struct { uint32_t count; uint32_t variant; uint32_t pre_init; uint32_t reserved; } reina_import_batch_t;
+/* `testing_mode`: the mode in force when the batch was imported.  Interventions of one date are applied in list order
+ * (main.pyx:2013-2015) and import-infections infects at once, so a `test-with-contact-tracing` LATER in the list of the
+ * same date does not give these imports an infectee list (person_infect, main.pyx:226-232), and one EARLIER does even
+ * if the day ends in another mode; weekly batches run after all interventions: the day's mode. */
+typedef struct { uint32_t count; uint32_t variant; uint32_t pre_init; uint32_t testing_mode; } reina_import_batch_t;
 /* vaccinate `nr` agents per day among sorted indices [idx_start, idx_end), oldest first
  * (HealthcareSystem.vaccinate_people main.pyx:560-583); `slot` keeps the device-side cursor */
 typedef struct { uint32_t nr; uint32_t idx_start; uint32_t idx_end; uint32_t slot; } reina_vaccination_t;
@@ -286,9 +290,9 @@ int reina_destroy(reina_engine_t *e);
 int reina_bind_buffers(reina_engine_t *e, const reina_buffers_t *buffers);
 int reina_init_state(reina_engine_t *e, int32_t hospital_beds, int32_t icu_units, void *stream);
 /* replaces Population.set_initial_state (main.pyx:1452-1516); call once, right after
- * reina_init_state and before the first day.  Parallel form: every slot draws a uniform agent (up
- * to 10 tries for a never-infected one, lowest slot wins a contested agent) instead of the
- * reference's draw with replacement; beds and ICU units are granted in slot order. */
+ * reina_init_state and before the first day.  Parallel form: every slot draws one uniform agent, with replacement
+ * like the reference; an agent drawn by several slots is visited by them in slot order (each visit moves the counters,
+ * the last one decides what the agent is); beds and ICU units are granted in slot order. */
 int reina_set_initial_state(reina_engine_t *e, const reina_initial_state_t *ic, void *stream);
 /* replaces ContactMatrix.generate_contact_probabilities upload (main.pyx:1184-1235) */
 int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t *t, void *stream);

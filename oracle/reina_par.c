@@ -215,7 +215,7 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
     float g = rp_gamma_mu_cv(e->dis.mean_incubation_duration[0], 0.86f, e->k0, e->k1, t, day, RP_P_INFECT, 1);
     uint32_t dl = clamp_days(e, rp_round_to_int(g));
     uint32_t nw = RS_INCUBATION | ((uint32_t)sev << 3) | (variant << 8) | (pod ? RH_POD_OUTSIDE : 0) |
-                  (w & RH_VACCINATED) |
+                  (w & (RH_VACCINATED | RH_DETECTED)) |   /* (was_detected outlives a re-infection: set_initial_state only) */
                   (testing_mode == RT_ALL_WITH_SYMPTOMS_CT ? RH_HASLIST : 0) | RH_ACTIVE |
                   /* (a FRESH agent of the initial condition sits out the scan of day 0 first) */
                   RH_DAYS_FIELD(dl, (fresh && day == RP_INIT_DAY) ? day + 1u : day) |
@@ -302,12 +302,16 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
         if ((int)dp->import_batches[b].pre_init == pre_init) total += dp->import_batches[b].count;
     if (!total) return;
     uint32_t *variant = (uint32_t *)malloc(sizeof(uint32_t) * total);
+    uint32_t *mode = (uint32_t *)malloc(sizeof(uint32_t) * total);   /* testing mode in force when the batch was imported */
     uint32_t *target = (uint32_t *)malloc(sizeof(uint32_t) * total);
     uint8_t *next_try = (uint8_t *)calloc(total, 1); /* 0..10; 255 = placed */
     uint32_t n = 0;
     for (uint32_t b = 0; b < dp->n_import_batches; b++)
         if ((int)dp->import_batches[b].pre_init == pre_init)
-            for (uint32_t k = 0; k < dp->import_batches[b].count; k++) variant[n++] = dp->import_batches[b].variant;
+            for (uint32_t k = 0; k < dp->import_batches[b].count; k++) {
+                mode[n] = dp->import_batches[b].testing_mode;
+                variant[n++] = dp->import_batches[b].variant;
+            }
     /* imports are worked off in chunks of 16384 (the HIP kernel's LDS bookkeeping), rounds per chunk */
     for (uint32_t c0 = 0; c0 < total; c0 += 16384u) {
     const uint32_t c1 = total - c0 < 16384u ? total : c0 + 16384u;
@@ -337,7 +341,7 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
             if (target[j] == 0xFFFFFFFFu) continue;
             uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
             if (e->buf.claim[target[j]] == key) {
-                install_infection(e, target[j], dp->day, variant[j], -1, 1, dp->testing_mode, 0);
+                install_infection(e, target[j], dp->day, variant[j], -1, 1, mode[j], 0);
                 next_try[j] = 255;
             }
         }
@@ -347,6 +351,7 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
         if (next_try[j] != 255) SC(e, REINA_S_UNABLE_TO_IMPORT) += 1;
     *import_base += total;
     free(variant);
+    free(mode);
     free(target);
     free(next_try);
 }
@@ -657,12 +662,14 @@ static void run_hospital_events(Par *e, const reina_day_t *dp) {
 
 /* ---------------------------------------------------------------- initial population condition */
 /* Population.set_initial_state (main.pyx:1452-1516), parallel form (include/reina_hip.h:
- * reina_set_initial_state).  Every slot owns up to 10 target draws keyed (slot, RP_INIT_DAY, try);
- * a contested agent goes to the lowest slot.  Capacity: ICU-fated slots come first and hand their
- * bed back when they move to ICU (hc.to_icu, main.pyx:641-646), so the r-th ICU slot gets a unit iff
- * r < units and the r-th ward slot a bed iff r < beds.  Not reproduced: the reference's second
- * visit of an agent drawn twice, and its transfer_to_icu of an agent who was just refused a bed
- * (only reachable with zero beds). */
+ * reina_set_initial_state).  Slot j draws ONE uniform agent, with replacement like get_random_person
+ * (main.pyx:1518-1520) -- an agent drawn by several slots is visited by them in slot order and ends as the last one
+ * leaves it, while every visit moves the counters (person_infect on an infected, recovered or dead person is
+ * what the reference does; in a 20 000-agent population with 430 initial agents that is 4.6 agents per run, and a
+ * later `recovered` slot takes out an earlier ill one: 1.4 % of the infectious seed).  Capacity: ICU-fated slots come
+ * first and hand their bed back when they move to ICU (hc.to_icu, main.pyx:641-646), so the r-th ICU slot gets a unit
+ * iff r < units and the r-th ward slot a bed iff r < beds.  Not reproduced: the reference's transfer_to_icu of an
+ * agent who was just refused a bed (only reachable with zero beds). */
 static int initial_target(Par *e, uint32_t slot, uint32_t k, uint32_t *t_out) {
     rp_u4 r = rp_philox(e->k0, e->k1, slot, RP_INIT_DAY, RP_P_INITIAL, k);
     *t_out = r.v[0] % e->cfg.n_agents;
@@ -676,40 +683,13 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
     const uint32_t i_inc = ic->incubating, i_rec = i_inc + ic->recovered_without_illness, i_ill = i_rec + ic->ill,
                    i_dead = i_ill + ic->dead, i_icu = i_dead + ic->in_icu, i_ward = i_icu + ic->in_ward;
     const reina_disease_t *d = &e->dis;
-    uint32_t *target = (uint32_t *)malloc(sizeof(uint32_t) * (M + 1));
-    uint8_t *next_try = (uint8_t *)calloc(M + 1, 1);
     int b = SC(e, REINA_S_AVAILABLE_BEDS), c = SC(e, REINA_S_AVAILABLE_ICU);
     const int beds0 = b, icu0 = c;
-    /* slots are worked off in chunks of 16384 (the HIP kernel's LDS bookkeeping), rounds per chunk */
-    for (uint32_t c0 = 0; c0 < M; c0 += 16384u) {
-    const uint32_t c1 = M - c0 < 16384u ? M : c0 + 16384u;
-    for (uint32_t round = 0; round < 10; round++) {
-        uint32_t proposals = 0;
-        for (uint32_t j = c0; j < c1; j++) {
-            target[j] = 0xFFFFFFFFu;
-            if (next_try[j] == 255) continue;
-            uint32_t k = next_try[j];
-            for (; k < 10; k++) {
-                uint32_t t;
-                if (initial_target(e, j, k, &t) && RH_STATE(e->buf.hot[t]) == RS_SUSCEPTIBLE) {
-                    target[j] = t;
-                    break;
-                }
-            }
-            next_try[j] = (uint8_t)(k < 10 ? k + 1 : 10);
-            if (target[j] != 0xFFFFFFFFu) proposals++;
-        }
-        if (!proposals) break;
-        for (uint32_t j = c0; j < c1; j++) {
-            if (target[j] == 0xFFFFFFFFu) continue;
-            uint64_t key = rp_order_key(0, 0xFFFFFu - round, j);
-            if (key < e->buf.claim[target[j]]) e->buf.claim[target[j]] = key;
-        }
-        for (uint32_t j = c0; j < c1; j++) {
-            if (target[j] == 0xFFFFFFFFu) continue;
-            const uint32_t t = target[j];
-            if (e->buf.claim[t] != rp_order_key(0, 0xFFFFFu - round, j)) continue;
-            next_try[j] = 255;
+    {
+    {
+        for (uint32_t j = 0; j < M; j++) {
+            uint32_t t;
+            initial_target(e, j, 0, &t);
             install_infection(e, t, RP_INIT_DAY, 0, -1, j < i_inc, RT_NO_TESTING, 0);
             if (j < i_inc) continue;
             uint32_t w = e->buf.hot[t];
@@ -726,9 +706,11 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
                 w = do_die(e, w, age);
             } else if (j < i_ward) {
                 const int to_icu = j < i_icu;
-                w |= RH_DETECTED;   /* person_hospitalize detects first (main.pyx:322-325) */
-                CNT(e, REINA_C_DETECTED, age) += 1;
-                CNT(e, REINA_C_ALL_DETECTED, age) += 1;
+                if (!(w & RH_DETECTED)) {   /* person_hospitalize detects first (main.pyx:322-325), once per person */
+                    w |= RH_DETECTED;
+                    CNT(e, REINA_C_DETECTED, age) += 1;
+                    CNT(e, REINA_C_ALL_DETECTED, age) += 1;
+                }
                 const int bed = to_icu ? beds0 > 0 : (int)(j - i_icu) < beds0;
                 if (!bed) {
                     w = dies_in_hospital(e, t, RP_INIT_DAY, sev, v, 0) ? do_die(e, w, age) : do_recover(e, w, age);
@@ -758,8 +740,6 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
         }
     }
     }
-    for (uint32_t j = 0; j < M; j++)
-        if (next_try[j] != 255) SC(e, REINA_S_UNABLE_TO_IMPORT) += 1;
     SC(e, REINA_S_AVAILABLE_BEDS) = b;
     SC(e, REINA_S_AVAILABLE_ICU) = c;
     /* main.pyx:1503-1516 */
@@ -767,8 +747,6 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
     const uint32_t stride = ic->confirmed_stride ? ic->confirmed_stride : 1;
     for (uint32_t i = ic->confirmed_first; i < ic->confirmed_cases; i += stride)
         if (i % 100 < e->cfg.nr_ages) CNT(e, REINA_C_ALL_DETECTED, i % 100) += 1;
-    free(target);
-    free(next_try);
     return 0;
 }
 

@@ -110,7 +110,7 @@ class InitialState(ctypes.Structure):
 
 class ImportBatch(ctypes.Structure):
     _fields_ = [('count', ctypes.c_uint32), ('variant', ctypes.c_uint32),
-                ('pre_init', ctypes.c_uint32), ('reserved', ctypes.c_uint32)]
+                ('pre_init', ctypes.c_uint32), ('testing_mode', ctypes.c_uint32)]
 
 
 class Vaccination(ctypes.Structure):

@@ -350,10 +350,15 @@ class Context:
         ic.dead = sp(int(ipc.dead))
         ic.in_icu = sp(int(ipc.in_icu))
         ic.in_ward = sp(int(ipc.in_ward))
-        rest = sp(int(ipc.were_incubating()) - int(ipc.incubating) - int(ipc.recovered_without_illness())
-                  - int(ipc.ill) - int(ipc.dead) - int(ipc.in_icu) - int(ipc.in_ward))
-        ic.were_incubating = (ic.incubating + ic.recovered_without_illness + ic.ill + ic.dead + ic.in_icu
-                              + ic.in_ward + max(rest, 0))
+        # The reference walks range(were_incubating()) over boundaries that add up to MORE than that when fewer people
+        # recovered than are incubating (recovered_without_illness() = were_incubating - were_ill = incubating, so the
+        # boundaries end at 2 * incubating + ill + dead + in_icu + in_ward): the walk then stops short and the LAST
+        # categories -- in ward, in ICU, ... -- lose slots (main.pyx:1456-1463, calc/datasets.py:120-134).  Otherwise the
+        # slots behind the last boundary recovered on their own.
+        rest = (int(ipc.were_incubating()) - int(ipc.incubating) - int(ipc.recovered_without_illness())
+                - int(ipc.ill) - int(ipc.dead) - int(ipc.in_icu) - int(ipc.in_ward))
+        ic.were_incubating = max(0, ic.incubating + ic.recovered_without_illness + ic.ill + ic.dead + ic.in_icu
+                                 + ic.in_ward + (sp(rest) if rest >= 0 else -sp(-rest)))
         ic.confirmed_cases = int(ipc.confirmed_cases)
         ic.confirmed_first = self.shard_rank
         ic.confirmed_stride = self.n_shards
@@ -402,7 +407,9 @@ class Context:
         elif t == 'build-new-hospital-beds':
             self._pending_beds += int(params['beds'])
         elif t == 'import-infections':
-            self._pending_imports.append((int(params['amount']), self.find_variant(params.get('variant')), 1))
+            # (the testing mode of THIS moment decides whether the imported agents keep an infectee list: interventions
+            # of one date are applied in list order, main.pyx:2013-2015)
+            self._pending_imports.append((int(params['amount']), self.find_variant(params.get('variant')), 1, self.testing_mode))
         elif t == 'import-infections-weekly':
             shares = [0] * len(self.variant_names)
             for pn in params.keys():
@@ -465,7 +472,7 @@ class Context:
             leftover = np.float32(float(leftover) + self.weekly_infections_amount / 7.0 * self.weekly_infections_shares[vid])
             amount_today = int(leftover)
             if amount_today:
-                weekly.append((amount_today, vid, 0))
+                weekly.append((amount_today, vid, 0, self.testing_mode))
                 leftover = np.float32(leftover - np.float32(amount_today))
             assert leftover >= 0
             self.weekly_infections_leftover[vid] = float(leftover)
@@ -486,10 +493,11 @@ class Context:
         if len(batches) > _eng.MAX_IMPORT_BATCHES:
             raise Exception('more than %d import batches in one day' % _eng.MAX_IMPORT_BATCHES)
         d.n_import_batches = len(batches)
-        for k, (count, variant, pre) in enumerate(batches):
+        for k, (count, variant, pre, mode) in enumerate(batches):
             d.import_batches[k].count = self._split(count)
             d.import_batches[k].variant = variant
             d.import_batches[k].pre_init = pre
+            d.import_batches[k].testing_mode = mode
         nv = 0
         pop_max_age = self.nr_ages - 1
         for v in self.vaccinations:

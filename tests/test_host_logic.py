@@ -253,3 +253,47 @@ def test_native_contact_table_builder_equals_numpy_form():
             for cm in (a, b):
                 cm.set_mobility_factor(f, place=place, min_age=lo, max_age=hi)
         same(a, b)
+
+
+def test_import_batches_carry_the_testing_mode_in_force_when_they_were_applied():
+    """interventions of one date run in list order (main.pyx:2013-2015); import-infections infects at once, so each
+    batch records the mode of that moment (it decides whether the imported agents keep an infectee list)"""
+    import copy
+    import par_backend
+    from reina_model_amd import datasets, engine as eng, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    d0 = v['start_date']
+    ivs = [['import-infections', d0, 5], ['test-with-contact-tracing', d0, 50], ['import-infections', d0, 7],
+           ['test-only-severe-symptoms', d0, 10], ['import-infections', d0, 9]]
+    ctx = simulation.make_context(v, age_counts=datasets.scaled_population(5000), seed=1, interventions=ivs,
+                                  engine_factory=par_backend.par_engine_factory, device='cpu')
+    day, _ = ctx._build_day(None)
+    got = [(b.count, b.testing_mode) for b in day.import_batches[:day.n_import_batches] if b.pre_init]
+    assert got == [(5, 0), (7, 1), (9, 3)], got      # TestingMode: none 0, tracing 1, all with symptoms 2, only severe 3
+    assert day.testing_mode == 3
+
+
+def test_initial_condition_walk_is_cut_short_like_the_reference_walks_it():
+    """recovered_without_illness() = were_incubating() - were_ill() = incubating (calc/datasets.py:120-134), so the slot
+    boundaries of set_initial_state (main.pyx:1456-1463) end at 2 * incubating + ill + dead + in_icu + in_ward while the
+    walk covers were_incubating() slots: with fewer recovered than incubating people the last categories lose slots"""
+    from reina_model_amd import datasets
+    ipc = datasets.InitialPopulationCondition(dead=2, in_icu=5, in_ward=7, confirmed_cases=135, incubating=45, ill=11, recovered=33)
+    assert ipc.recovered_without_illness() == 45 and ipc.were_incubating() == 103
+    seen = {}
+
+    class Eng:
+        def set_initial_state(self, ic):
+            seen['ic'] = ic
+    from reina_model_amd import model
+    ctx = model.Context.__new__(model.Context)
+    ctx._split = lambda x: x
+    ctx.shard_rank, ctx.n_shards, ctx.engine = 0, 1, Eng()
+    ctx._set_initial_state(ipc)
+    ic = seen['ic']
+    assert ic.were_incubating == 103                      # not 45 + 45 + 11 + 2 + 5 + 7 = 115: ward and ICU slots are lost
+    assert ic.incubating + ic.recovered_without_illness + ic.ill + ic.dead == 103
+    ipc2 = datasets.InitialPopulationCondition(dead=5, in_icu=4, in_ward=12, incubating=60, ill=45, recovered=300)
+    ctx._set_initial_state(ipc2)
+    assert seen['ic'].were_incubating == ipc2.were_incubating() == 426
