@@ -788,8 +788,12 @@ static void iterate_people(Sim *s) {
 /* Population.set_initial_state main.pyx:1452-1516 (+ get_random_person :1518-1521).  The caller
  * passes the InitialPopulationCondition numbers (calc/datasets.py:106-134); persons are drawn
  * WITH replacement and without any state check, exactly like the reference. */
-void seq_set_initial_state(Sim *s, int incubating, int recovered_without_illness, int ill, int dead,
-                           int in_icu, int in_ward, int were_incubating, int confirmed_cases) {
+/* returns 1 where the reference raises AssertionError out of Context.__init__: an ICU-fated agent who was refused a bed
+ * (person_hospitalize left it dead or recovered) goes on to person_transfer_to_icu, whose Population.transfer_to_icu /
+ * release_from_hospital assert state == HOSPITALIZED (main.pyx:1495 -> :350 -> :1603, :1613) -- i.e. an initial condition
+ * with people in ICU and a hospital without beds cannot be constructed */
+int seq_set_initial_state(Sim *s, int incubating, int recovered_without_illness, int ill, int dead,
+                          int in_icu, int in_ward, int were_incubating, int confirmed_cases) {
     int i_incubating = incubating;
     int i_recovered_without_symptoms = i_incubating + recovered_without_illness;
     int i_ill_at_home = i_recovered_without_symptoms + ill;
@@ -812,6 +816,7 @@ void seq_set_initial_state(Sim *s, int incubating, int recovered_without_illness
         }
         if (i < i_in_icu) {
             person_hospitalize(s, person);
+            if (person->state != HOSPITALIZED) return 1;   /* the assertion of the reference */
             person_transfer_to_icu(s, person);
             continue;
         }
@@ -826,6 +831,7 @@ void seq_set_initial_state(Sim *s, int incubating, int recovered_without_illness
         int age = (100 + i) % 100;
         if (age < s->nr_ages) s->cnt[C_ALL_DETECTED][age] += 1;
     }
+    return 0;
 }
 
 /* Context._iterate main.pyx:1994-2009; returns the problem code (iterate() raises on != 0) */

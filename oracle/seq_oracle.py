@@ -108,6 +108,7 @@ def lib():
         L.seq_set_testing_mode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
         L.seq_add_beds.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.seq_set_initial_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8
+        L.seq_set_initial_state.restype = ctypes.c_int
         L.seq_add_icu_units.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.seq_infect_people.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.seq_infect_weekly.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -254,9 +255,12 @@ class Context:
         self._L = L
         # main.pyx:1780-1781: the initial condition is applied last, before any intervention exists
         if ipc is not None and ipc.has_initial_state():
-            L.seq_set_initial_state(self._h, int(ipc.incubating), int(ipc.recovered_without_illness()), int(ipc.ill),
-                                    int(ipc.dead), int(ipc.in_icu), int(ipc.in_ward), int(ipc.were_incubating()),
-                                    int(ipc.confirmed_cases))
+            if L.seq_set_initial_state(self._h, int(ipc.incubating), int(ipc.recovered_without_illness()), int(ipc.ill),
+                                       int(ipc.dead), int(ipc.in_icu), int(ipc.in_ward), int(ipc.were_incubating()),
+                                       int(ipc.confirmed_cases)):
+                # what cythonsim does (recorded in the build container: Context.__init__ -> set_initial_state main.pyx:1495
+                # -> person_transfer_to_icu :350 -> Population.transfer_to_icu :1603 `assert person.state == HOSPITALIZED`)
+                raise AssertionError('initial population condition: an agent bound for ICU was refused a hospital bed')
 
     def __del__(self):
         h = getattr(self, '_h', None)

@@ -342,6 +342,15 @@ class Context:
     def _set_initial_state(self, ipc):
         """Population.set_initial_state (main.pyx:1452-1516) on the engine; a sharded population
         applies each shard's share of every number."""
+        # An ICU-fated agent takes a bed first and hands it back when it moves on (hc.to_icu), so it is refused one iff the
+        # hospital has NO beds -- and then the reference does not construct: person_hospitalize leaves the agent dead or
+        # recovered, person_transfer_to_icu follows, and Population.transfer_to_icu / release_from_hospital assert
+        # state == HOSPITALIZED (AssertionError out of Context.__init__, main.pyx:1781 -> :1495 -> :350 -> :1603; recorded
+        # with the real reference in the build container).  Same answer here, for every shard alike (global numbers).
+        i_dead = 2 * int(ipc.incubating) + int(ipc.ill) + int(ipc.dead)   # (recovered_without_illness() == incubating)
+        icu_slots = max(0, min(i_dead + int(ipc.in_icu), int(ipc.were_incubating())) - i_dead)
+        if icu_slots > 0 and int(self.beds) == 0:
+            raise AssertionError('initial population condition: an agent bound for ICU was refused a hospital bed')
         ic = _eng.InitialState()
         sp = self._split
         ic.incubating = sp(int(ipc.incubating))

@@ -289,7 +289,7 @@ def test_initial_condition_walk_is_cut_short_like_the_reference_walks_it():
     from reina_model_amd import model
     ctx = model.Context.__new__(model.Context)
     ctx._split = lambda x: x
-    ctx.shard_rank, ctx.n_shards, ctx.engine = 0, 1, Eng()
+    ctx.shard_rank, ctx.n_shards, ctx.engine, ctx.beds = 0, 1, Eng(), 10
     ctx._set_initial_state(ipc)
     ic = seen['ic']
     assert ic.were_incubating == 103                      # not 45 + 45 + 11 + 2 + 5 + 7 = 115: ward and ICU slots are lost
