@@ -347,27 +347,27 @@ class Context:
         # recovered, person_transfer_to_icu follows, and Population.transfer_to_icu / release_from_hospital assert
         # state == HOSPITALIZED (AssertionError out of Context.__init__, main.pyx:1781 -> :1495 -> :350 -> :1603; recorded
         # with the real reference in the build container).  Same answer here, for every shard alike (global numbers).
-        i_dead = 2 * int(ipc.incubating) + int(ipc.ill) + int(ipc.dead)   # (recovered_without_illness() == incubating)
-        icu_slots = max(0, min(i_dead + int(ipc.in_icu), int(ipc.were_incubating())) - i_dead)
-        if icu_slots > 0 and int(self.beds) == 0:
-            raise AssertionError('initial population condition: an agent bound for ICU was refused a hospital bed')
-        ic = _eng.InitialState()
-        sp = self._split
-        ic.incubating = sp(int(ipc.incubating))
-        ic.recovered_without_illness = sp(int(ipc.recovered_without_illness()))
-        ic.ill = sp(int(ipc.ill))
-        ic.dead = sp(int(ipc.dead))
-        ic.in_icu = sp(int(ipc.in_icu))
-        ic.in_ward = sp(int(ipc.in_ward))
         # The reference walks range(were_incubating()) over boundaries that add up to MORE than that when fewer people
         # recovered than are incubating (recovered_without_illness() = were_incubating - were_ill = incubating, so the
         # boundaries end at 2 * incubating + ill + dead + in_icu + in_ward): the walk then stops short and the LAST
         # categories -- in ward, in ICU, ... -- lose slots (main.pyx:1456-1463, calc/datasets.py:120-134).  Otherwise the
-        # slots behind the last boundary recovered on their own.
-        rest = (int(ipc.were_incubating()) - int(ipc.incubating) - int(ipc.recovered_without_illness())
-                - int(ipc.ill) - int(ipc.dead) - int(ipc.in_icu) - int(ipc.in_ward))
-        ic.were_incubating = max(0, ic.incubating + ic.recovered_without_illness + ic.ill + ic.dead + ic.in_icu
-                                 + ic.in_ward + (sp(rest) if rest >= 0 else -sp(-rest)))
+        # slots behind the last boundary recovered on their own.  The slots each category keeps are worked out for the
+        # WHOLE population first and divided among the shards afterwards.
+        M = int(ipc.were_incubating())
+        widths = [int(ipc.incubating), int(ipc.recovered_without_illness()), int(ipc.ill), int(ipc.dead), int(ipc.in_icu),
+                  int(ipc.in_ward)]
+        kept, lo = [], 0
+        for w in widths:
+            kept.append(max(0, min(lo + w, M) - lo))
+            lo += w
+        rest = max(0, M - lo)
+        if kept[4] > 0 and int(self.beds) == 0:
+            raise AssertionError('initial population condition: an agent bound for ICU was refused a hospital bed')
+        ic = _eng.InitialState()
+        sp = self._split
+        (ic.incubating, ic.recovered_without_illness, ic.ill, ic.dead, ic.in_icu, ic.in_ward) = [sp(k) for k in kept]
+        ic.were_incubating = (ic.incubating + ic.recovered_without_illness + ic.ill + ic.dead + ic.in_icu + ic.in_ward
+                              + sp(rest))
         ic.confirmed_cases = int(ipc.confirmed_cases)
         ic.confirmed_first = self.shard_rank
         ic.confirmed_stride = self.n_shards

@@ -8,7 +8,8 @@ A scenario counts as a failure only if an independent second seed set confirms i
 have heavy-tailed outcomes, and one seed set of 250 runs has produced z = 5 there from an early fluctuation that the
 next three sets did not show.
 (Test infrastructure: it drives both oracles, so it lives under tests/; tests/test_par_vs_seq.py runs a few cases.)
-usage: python tests/diff_a_b.py [first_case] [n_cases] [n_seeds]"""
+usage: python tests/diff_a_b.py [first_case] [n_cases] [n_seeds] [shards]   (shards > 1: oracle B split over that many
+in-process shards, compared on everything that does not pass through the partitioned bed / ICU pools)"""
 import os
 import sys
 
@@ -73,7 +74,35 @@ def series(ctx, days, ck):
     return out
 
 
-def compare_case(case, n, seed0=0, scenario=None):
+# what a sharded run is compared on: everything that does not pass through the partitioned bed / ICU pools (their
+# day-granular split is a documented deviation)
+NOT_CAPACITY = ('susceptible', 'vaccinated', 'infected', 'all_infected', 'detected', 'all_detected', 'new_infections', 'r',
+                'exposed_per_day', 'ct_cases_per_day', 'daily_contacts', 'variant0', 'variant1')
+
+
+class ShardedB:
+    """G in-process shards of oracle B behind the generate_state() / iterate() pair of one Context"""
+    def __init__(self, v, ages, seed, ivs, ipc, G):
+        from reina_model_amd import sharding
+        self.sh = sharding
+        members = []
+        self.ctxs = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=ivs, ipc=ipc, device='cpu',
+                                             engine_factory=par_backend.par_engine_factory,
+                                             comm=sharding.InProcessComm(r, G, members)) for r in range(G)]
+
+    def generate_state(self):
+        return self.ctxs[0].state_from_counters(self.sh.reduce_counters(self.ctxs))
+
+    def iterate(self):
+        self.sh.step_shards_together(self.ctxs)
+        from reina_model_amd.model import SimulationFailed
+        c = self.sh.reduce_counters(self.ctxs)
+        from reina_model_amd import engine as eng
+        if c[eng.C_NR * eng.MAX_AGES + eng.S_PROBLEM]:
+            raise SimulationFailed('problem %d' % c[eng.C_NR * eng.MAX_AGES + eng.S_PROBLEM])
+
+
+def compare_case(case, n, seed0=0, scenario=None, shards=1):
     """`scenario`: (variables, age_counts, days, interventions, ipc) instead of random scenario number `case`"""
     if scenario is None:
         rng = np.random.default_rng(1000 + case)
@@ -98,8 +127,11 @@ def compare_case(case, n, seed0=0, scenario=None):
                 failed += 1
         return out, failed
     A, fa = runs(lambda s: so.make_context(v, ages, seed0 + 500 + s, interventions=ivs, ipc=ipc))
-    B, fb = runs(lambda s: simulation.make_context(v, age_counts=ages, seed=seed0 + 900 + s, interventions=ivs, ipc=ipc, device='cpu',
-                                                   engine_factory=par_backend.par_engine_factory))
+    if shards > 1:
+        B, fb = runs(lambda s: ShardedB(v, ages, seed0 + 900 + s, ivs, ipc, shards))
+    else:
+        B, fb = runs(lambda s: simulation.make_context(v, age_counts=ages, seed=seed0 + 900 + s, interventions=ivs, ipc=ipc, device='cpu',
+                                                       engine_factory=par_backend.par_engine_factory))
     # a scenario that makes the model raise (e.g. 'Wrong state' on a change of testing mode): both oracles must raise
     # about equally often (binomial z); the runs that completed are compared like any others if enough are left
     zf = 0.0
@@ -115,7 +147,11 @@ def compare_case(case, n, seed0=0, scenario=None):
     res = []
     for di, d in enumerate(ck):
         for k, name in enumerate(names):
+            if shards > 1 and name not in NOT_CAPACITY:
+                continue
             a, b = A[:, di, k], B[:, di, k]
+            if shards > 1 and name == 'vaccinated' and abs(b.mean() - a.mean()) <= 0.002 * a.mean():
+                continue   # per-shard daily quotas: the vaccination front may differ by a few agents on a given day
             pooled = (a.mean() + b.mean()) / 2
             se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
             if se == 0:
@@ -132,14 +168,14 @@ def compare_case(case, n, seed0=0, scenario=None):
                 n_cmp=len(res), worst=res[:4], all=res, types=sorted(set(iv[0] for iv in ivs)))
 
 
-def confirmed_failure(case, n, scenario=None):
+def confirmed_failure(case, n, scenario=None, shards=1):
     """(failed, first report, confirming report or None): outside Z_MAX in one seed set AND beyond 3 sigma with the same
     sign for the same (day, quantity) in an independent second one"""
-    r = compare_case(case, n, scenario=scenario)
+    r = compare_case(case, n, scenario=scenario, shards=shards)
     w = r['worst'][0]
     if not abs(w[0]) > Z_MAX:
         return False, r, None
-    r2 = compare_case(case, n, seed0=100000, scenario=scenario)
+    r2 = compare_case(case, n, seed0=100000, scenario=scenario, shards=shards)
     again = [x for x in r2['all'] if x[1] == w[1] and x[2] == w[2]]
     same = bool(again) and (again[0][0] * w[0] > 0) and abs(again[0][0]) > 3.0
     return same, r, r2
@@ -149,9 +185,10 @@ if __name__ == '__main__':
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 48
+    G = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     bad = 0
     for case in range(first, first + cases):
-        failed, r, r2 = confirmed_failure(case, n)
+        failed, r, r2 = confirmed_failure(case, n, shards=G)
         flag = 'FAIL' if failed else ('ok? ' if r2 is not None else 'ok  ')
         bad += failed
         print('%s case %3d agents %6d days %3d beds %2d icu %d ipc %d  %4d comparisons; worst: %s' % (

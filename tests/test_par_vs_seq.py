@@ -166,6 +166,18 @@ def test_randomised_scenarios_against_the_sequential_oracle(case):
 
 
 @pytest.mark.slow
+@pytest.mark.parametrize('case', [3, 25])
+def test_randomised_scenarios_on_three_shards_against_the_sequential_oracle(case):
+    """the same with oracle B split over three in-process shards (an odd number: every quota leaves a remainder), compared
+    on everything that does not pass through the partitioned bed / ICU pools; case 25 is the initial condition whose
+    walk stops short -- the slots each category keeps are worked out for the whole population, then divided"""
+    import diff_a_b
+    failed, r, r2 = diff_a_b.confirmed_failure(case, 24, shards=3)
+    assert r['n_cmp'] > 60, r
+    assert not failed, (r['worst'], r2 and r2['worst'])
+
+
+@pytest.mark.slow
 def test_an_import_sees_the_testing_mode_of_its_place_in_the_list():
     """Interventions of one date are applied in list order (main.pyx:2013-2015) and `import-infections` infects at once:
     imports listed BEFORE a `test-with-contact-tracing` of the same date get no infectee list, so tracing cannot walk
