@@ -292,7 +292,10 @@ int reina_init_state(reina_engine_t *e, int32_t hospital_beds, int32_t icu_units
 /* replaces Population.set_initial_state (main.pyx:1452-1516); call once, right after
  * reina_init_state and before the first day.  Parallel form: every slot draws one uniform agent, with replacement
  * like the reference; an agent drawn by several slots is visited by them in slot order (each visit moves the counters,
- * the last one decides what the agent is); beds and ICU units are granted in slot order. */
+ * the last one decides what the agent is); beds and ICU units are granted in slot order.  Precondition (the caller's to
+ * check, for the whole population when the engine is a shard): if `in_icu` > 0 the hospital has at least one bed -- the
+ * reference raises AssertionError out of Context.__init__ otherwise (main.pyx:1495 -> :350 -> :1603), and so does
+ * reina_model_amd.model.Context. */
 int reina_set_initial_state(reina_engine_t *e, const reina_initial_state_t *ic, void *stream);
 /* replaces ContactMatrix.generate_contact_probabilities upload (main.pyx:1184-1235) */
 int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t *t, void *stream);

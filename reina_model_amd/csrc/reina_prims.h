@@ -344,5 +344,6 @@ RP_HD int32_t rp_capacity_share(const int32_t *words, uint32_t n_shards, uint32_
 #define RP_REMOTE_SRC 0x80000000u
 #define RP_MIRROR_PROBES 16u      // probes per cell of the mirror table (tables are kept >= ~40 % full)
 #define RP_MIRROR_MIN_SLOTS 8u    // smallest table: fully scanned by one lookup
+#define RP_MIRROR_STALE_DAYS 14u   // a stand-in infector may be an agent that aimed at another shard up to this many days ago
 
 #endif  // REINA_PRIMS_H
