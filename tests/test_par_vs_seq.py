@@ -195,3 +195,36 @@ def test_an_import_sees_the_testing_mode_of_its_place_in_the_list():
     for d in (20, 40):
         z, a, b = by[(d, 'all_infected')]
         assert abs(z) <= 4.5 and abs(b - a) <= 0.08 * a, (d, z, a, b)
+
+
+def test_small_outbreaks_on_shards_keep_their_infector_links():
+    """With a handful of infectious agents per shard there are days on which nobody on a shard aims at another shard, and
+    an infection arriving from elsewhere found no stand-in infector among the day's outgoing attempts: one in ten
+    (32 of 280 by day 38 in this scenario, 4 shards) stayed outside every infectee list, out of contact tracing's reach.
+    The lookup falls back to the most recent entry of the last RP_MIRROR_STALE_DAYS days: every infection but the
+    imports has an infector link again, as in the reference."""
+    import copy
+    import par_backend
+    from reina_model_amd import datasets, sharding, simulation
+    from reina_model_amd.variables import VARIABLE_DEFAULTS
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=19, icu_units=1, infectiousness_multiplier=0.343)
+    d0 = v['start_date']
+    ivs = [['import-infections', d0, 67], ['test-only-severe-symptoms', '2020-02-23', 76], ['test-with-contact-tracing', '2020-02-28', 92]]
+    ages = datasets.scaled_population(31349)
+    with_link = without = 0
+    for seed in range(6):
+        members = []
+        ctxs = [simulation.make_context(v, age_counts=ages, seed=900 + seed, interventions=ivs, device='cpu',
+                                        engine_factory=par_backend.par_engine_factory, comm=sharding.InProcessComm(r, 4, members))
+                for r in range(4)]
+        for _ in range(38):
+            sharding.step_shards_together(ctxs)
+        for c in ctxs:
+            hot = np.asarray(c.engine.tensors['hot']).view(np.uint32)
+            infector = np.asarray(c.engine.tensors['infector'])
+            ever = (hot & 7) != 0
+            with_link += int((ever & (infector >= 0)).sum())
+            without += int((ever & (infector < 0)).sum())
+    assert with_link > 6 * 100, with_link
+    assert without <= 6 * 67 + 0.02 * with_link, (without, with_link)    # the 67 imports of every run have none
