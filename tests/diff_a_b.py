@@ -57,6 +57,29 @@ def perturb_disease(v, rng):
     v['imported_infection_ages'] = [[a, float(100.0 * x / w.sum())] for (a, _), x in zip(v['imported_infection_ages'], w)]
 
 
+EXTREME_FROM = 7000   # cases from here on: small populations driven hard (the generator of test_extreme_random_scenarios)
+
+
+def extreme(v, ages, days, ivs, ipc, rng):
+    """imports of the order of the population (placement failures, susceptibles running out), infectiousness
+    multipliers up to 3, hardly any beds, contact tracing at full efficiency"""
+    from datetime import date, timedelta
+    from reina_model_amd import datasets
+    total = int(rng.integers(600, 6000))
+    ages = datasets.scaled_population(total)
+    v['infectiousness_multiplier'] = float(rng.uniform(1.0, 3.0))
+    v['variants'] = [{'name': 'b1.1.7', 'infectiousness_multiplier': float(rng.uniform(1.5, 3.0))}]
+    v['hospital_beds'] = int(rng.integers(0, 3))
+    v['icu_units'] = int(rng.integers(0, 2))
+    d0 = date.fromisoformat(v['start_date'])
+    ivs = list(ivs) + [['import-infections', (d0 + timedelta(days=int(rng.integers(0, 20)))).isoformat(), int(total * rng.uniform(0.2, 1.5))],
+                       ['import-infections-weekly', (d0 + timedelta(days=int(rng.integers(0, 30)))).isoformat(), int(total * rng.uniform(0.1, 2.0)), int(rng.integers(0, 101))],
+                       ['test-with-contact-tracing', (d0 + timedelta(days=int(rng.integers(0, 30)))).isoformat(), 100]]
+    if ipc is not None:
+        ipc = {k: min(val, total // 12) for k, val in ipc.items()}
+    return v, ages, min(days, 90), ivs, ipc
+
+
 def check_days(days):
     return sorted(set([d for d in (0, 1, 2, 3, 5, 7) if d < days] + list(range(10, days, 10)) + [days - 1]))
 
@@ -107,8 +130,10 @@ def compare_case(case, n, seed0=0, scenario=None, shards=1):
     if scenario is None:
         rng = np.random.default_rng(1000 + case)
         v, ages, days, ivs, ipc = tp._random_scenario(rng)
-        if case >= PERTURB_FROM:
+        if PERTURB_FROM <= case < EXTREME_FROM:
             perturb_disease(v, rng)
+        if case >= EXTREME_FROM:
+            v, ages, days, ivs, ipc = extreme(v, ages, days, ivs, ipc, rng)
     else:
         v, ages, days, ivs, ipc = scenario
     ivs = [[str(x) if isinstance(x, np.str_) else x for x in iv] for iv in ivs]
