@@ -304,7 +304,7 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
     uint32_t *variant = (uint32_t *)malloc(sizeof(uint32_t) * total);
     uint32_t *mode = (uint32_t *)malloc(sizeof(uint32_t) * total);   /* testing mode in force when the batch was imported */
     uint32_t *target = (uint32_t *)malloc(sizeof(uint32_t) * total);
-    uint8_t *next_try = (uint8_t *)calloc(total, 1); /* 0..10; 255 = placed */
+    uint8_t *next_try = (uint8_t *)calloc(total, 1); /* 255 = placed */
     uint32_t n = 0;
     for (uint32_t b = 0; b < dp->n_import_batches; b++)
         if ((int)dp->import_batches[b].pre_init == pre_init)
@@ -312,41 +312,18 @@ static void run_imports(Par *e, const reina_day_t *dp, int pre_init, uint32_t *i
                 mode[n] = dp->import_batches[b].testing_mode;
                 variant[n++] = dp->import_batches[b].variant;
             }
-    /* imports are worked off in chunks of 16384 (the HIP kernel's LDS bookkeeping), rounds per chunk */
-    for (uint32_t c0 = 0; c0 < total; c0 += 16384u) {
-    const uint32_t c1 = total - c0 < 16384u ? total : c0 + 16384u;
-    for (uint32_t round = 0; round < 10; round++) {
-        uint32_t proposals = 0;
-        for (uint32_t j = c0; j < c1; j++) {
-            target[j] = 0xFFFFFFFFu;
-            if (next_try[j] == 255) continue;
-            uint32_t k = next_try[j];
-            for (; k < 10; k++) {
-                uint32_t t;
-                if (import_target(e, dp, *import_base + j, k, &t) && RH_STATE(e->buf.hot[t]) == RS_SUSCEPTIBLE) {
-                    target[j] = t;
-                    break;
-                }
-            }
-            next_try[j] = (uint8_t)(k < 10 ? k + 1 : 10);
-            if (target[j] != 0xFFFFFFFFu) proposals++;
-        }
-        if (!proposals) break;
-        for (uint32_t j = c0; j < c1; j++) {
-            if (target[j] == 0xFFFFFFFFu) continue;
-            uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
-            if (key < e->buf.claim[target[j]]) e->buf.claim[target[j]] = key;
-        }
-        for (uint32_t j = c0; j < c1; j++) {
-            if (target[j] == 0xFFFFFFFFu) continue;
-            uint64_t key = rp_order_key(dp->day, 0xFFFFFu - round, j);
-            if (e->buf.claim[target[j]] == key) {
-                install_infection(e, target[j], dp->day, variant[j], -1, 1, mode[j], 0);
+    /* Population.infect_people (main.pyx:1652-1665) as the reference runs it: one import after the other, each taking the
+     * first of its <= 10 tries that hits a still susceptible agent.  (The HIP kernel reaches the same placement as a stable
+     * matching -- targets prefer lower import numbers, imports earlier tries -- k_open.inc: pro_imports.) */
+    for (uint32_t j = 0; j < total; j++)
+        for (uint32_t k = 0; k < 10; k++) {
+            uint32_t t;
+            if (import_target(e, dp, *import_base + j, k, &t) && RH_STATE(e->buf.hot[t]) == RS_SUSCEPTIBLE) {
+                install_infection(e, t, dp->day, variant[j], -1, 1, mode[j], 0);
                 next_try[j] = 255;
+                break;
             }
         }
-    }
-    }
     for (uint32_t j = 0; j < total; j++)
         if (next_try[j] != 255) SC(e, REINA_S_UNABLE_TO_IMPORT) += 1;
     *import_base += total;
