@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import test_parity_gpu as T
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+OFF = int(os.environ.get('REINA_SOAK_OFFSET', '0'))   # other scenarios than the last soak's
 bad = 0
 t0 = time.time()
 if len(sys.argv) > 2 and sys.argv[2] == 'sharded':
@@ -12,7 +13,7 @@ if len(sys.argv) > 2 and sys.argv[2] == 'sharded':
     import par_backend
     from reina_model_amd import sharding, simulation
     for case in range(n):
-        rng = np.random.default_rng(300000 + case)
+        rng = np.random.default_rng(300000 + OFF + case)
         v, ages, days, ivs, ipc = T._random_scenario(rng)
         G = int(rng.integers(2, 5))
         seed = int(rng.integers(0, 2 ** 31))
@@ -45,7 +46,7 @@ for case in range(n):
     if case % 250 == 249:
         print('soak: %d scenarios so far, %d mismatches, %.0f s' % (2 * (case + 1), bad, time.time() - t0), flush=True)
     for kind, seed0 in (('random', 100000), ('extreme', 200000)):
-        rng = np.random.default_rng(seed0 + case)
+        rng = np.random.default_rng(seed0 + OFF + case)
         v, ages, days, ivs, ipc = T._random_scenario(rng)
         try:
             if kind == 'extreme':
