@@ -365,6 +365,29 @@ def test_initial_population_condition(beds, icu, n, ipc):
     _assert_state_equal(gpu, cpu)
 
 
+@pytest.mark.parametrize('n,ipc', [
+    (2000, dict(dead=40, in_icu=30, in_ward=60, confirmed_cases=500, incubating=300, ill=400, recovered=2200)),
+    (30000, dict(dead=500, in_icu=300, in_ward=900, confirmed_cases=9000, incubating=4000, ill=6000, recovered=29000))])
+def test_initial_condition_with_more_slots_than_agents(n, ipc):
+    """the reference draws the agents of the initial condition with replacement: with more slots than agents (3030 on
+    2000; 40 700 -- three slot chunks -- on 30 000) most agents are visited several times, in slot order over many claim
+    rounds, every visit moving the counters -- construction and 30 days, HIP == oracle B bit for bit"""
+    import par_backend
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=25, icu_units=10, p_icu_death_no_beds=50.0)
+    ages = datasets.scaled_population(n)
+    gpu = simulation.make_context(v, age_counts=ages, seed=21, ipc=ipc)
+    cpu = simulation.make_context(v, age_counts=ages, seed=21, ipc=ipc, engine_factory=par_backend.par_engine_factory)
+    cg, cc = gpu.engine.read_counters(), cpu.engine.read_counters()
+    assert np.array_equal(cg, cc)
+    A = eng.MAX_AGES
+    slots = sum(ipc[k] for k in ('dead', 'in_icu', 'in_ward', 'incubating', 'ill', 'recovered'))
+    assert cg[eng.C_NAMES.index('all_infected') * A:][:A].sum() == slots > n      # every visit counts (Population.infect)
+    _assert_state_equal(gpu, cpu)
+    assert np.array_equal(gpu.run(30), cpu.run(30))
+    _assert_state_equal(gpu, cpu)
+
+
 def test_large_bed_event_sets():
     """An unmitigated wave in 2.5 M agents with few beds: thousands of bed / ICU events per day
     while capacity binds, i.e. the counting-sort path of the event walk (more than 1024 ordered
