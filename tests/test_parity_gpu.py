@@ -404,6 +404,22 @@ def test_large_bed_event_sets():
     assert c['all_infected'].sum() > 1_000_000   # the wave is big enough for > 1024 events a day
 
 
+def test_one_workgroup_event_walk_through_every_bucket_size():
+    """The same unmitigated wave in 1.0 M agents: a population the ONE-workgroup event walk serves (k_hosp_install,
+    16 priority buckets), whose ordered days grow from a few events per bucket (one key per lane of the wave that sorts
+    the bucket) through 65-128 and 129-256 keys (two / four per lane) to more than 256 (the workgroup's network over runs
+    of buckets) -- HIP == oracle B bit for bit, and the busiest ordered day really is past 256 keys a bucket."""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=360, icu_units=24, infectiousness_multiplier=1.0)
+    v['p_severe'] = [[a, min(60.0, 3.0 * x)] for a, x in v['p_severe']]   # (three times the hospital traffic: 6283 events on the busiest ordered day)
+    ivs = [['import-infections', '2020-02-19', 1200], ['import-infections', '2020-02-25', 1200, 'b1.1.7'],
+           ['test-all-with-symptoms', '2020-02-20']]
+    ages = datasets.scaled_population(1_000_000)
+    gpu, cpu = _run_and_compare(v, ages, 3, 100, interventions=ivs, chunk=25)
+    peak = int(gpu.engine.alloc.to_host(gpu.engine.tensors['control'])[eng.L_HOSP_PEAK])
+    assert 16 * 256 < peak < 15000, peak
+
+
 def test_sharded_population_at_config3_scale():
     """BASELINE configs[3] shape on one GPU: 4 shards x 25 M agents (10^8 in total) stepped in
     lock-step through the epidemic peak -- capacities of the cross-shard candidate region, the
