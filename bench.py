@@ -110,6 +110,14 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
         pre.synchronize()
         pre.engine.profile_read_kernels()
         del pre
+    # A Context is part of reference cycles: the throw-away ones die when the collector gets to them -- destroying
+    # their engines (hipFree of a hundred MB each, event destruction: synchronising calls) -- and if that happens inside a
+    # short timed window it doubles it (tools/short_window.py: 20 steps took 39-41 us each, or 52-65 right after a
+    # collection that freed a Context).  Collect them here, before the measured simulation exists, and keep the
+    # collector off while the clock runs.
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     ctx = simulation.make_context(variables, age_counts=ages, seed=seed, device=device, comm=comm)
     # the event-timed launch path is switched on BEFORE the warm-up so its one-time costs (event
     # pool, first timestamped dispatches) are not billed to the timed region
@@ -121,12 +129,14 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.disable()
     t0 = time.perf_counter()
     hist = ctx.run(steps, record_history=True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
+    gc.enable()
     prof = ctx.engine.profile_read_kernels()
     ctx.engine.profile_enable(False)
     A = eng.MAX_AGES
