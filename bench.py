@@ -107,6 +107,7 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
         pre = simulation.make_context(variables, age_counts=ages, seed=seed + 1000003 + rep, device=device, comm=comm)
         pre.engine.profile_enable(stride)
         pre.run(preheat, record_history=True)
+        pre.run(min(steps, 64), record_history=True)   # a read-back of the timed run's size class too (its pinned staging block)
         pre.synchronize()
         pre.engine.profile_read_kernels()
         del pre

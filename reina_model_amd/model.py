@@ -577,7 +577,7 @@ class Context:
         continue a replayed simulation with further plans of that same planner."""
         days = plan['days']
         a = self.engine.alloc
-        hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None
+        hist = self._history_buffer(days) if record_history else None
         base = a.ptr(hist) if record_history else None
         done = 0
         for tables, arr, n in plan['segments']:
@@ -589,10 +589,20 @@ class Context:
         self.mobility_history = plan['mobility_history']
         self.day = plan['start_day'] + days
         if record_history:
-            out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
-            self._raise_on_problem(self.engine.read_counters())
-            return out
+            return self._history_to_host(hist, days)
         return None
+
+    def _history_buffer(self, days):
+        """`days` history rows (each written whole by its day's opening launch: no memset) + one for the counters after the
+        last day, so that rows and problem flag come back in ONE copy and one wait"""
+        return self.engine.alloc.empty((days + 1) * _eng.COUNTER_WORDS, np.int32)
+
+    def _history_to_host(self, hist, days):
+        a = self.engine.alloc
+        a.copy_into(hist, days * _eng.COUNTER_WORDS, self.engine.tensors['counters'])
+        out = a.to_host(hist).reshape(days + 1, _eng.COUNTER_WORDS)
+        self._raise_on_problem(out[days])
+        return out[:days]
 
     def _run_streamed(self, days, record_history):
         """run() for an unsharded population, or a sharded one whose engine queues the per-day
@@ -601,7 +611,10 @@ class Context:
         turning the intervention schedule into the later ones (table uploads are queued copies from
         pinned staging, they do not drain the stream either)."""
         a = self.engine.alloc
-        hist = a.zeros(days * _eng.COUNTER_WORDS, np.int32) if record_history else None
+        single = self.n_shards == 1 and not self.always_collective
+        hist = None
+        if record_history:
+            hist = self._history_buffer(days) if single else a.zeros(days * _eng.COUNTER_WORDS, np.int32)
         base = a.ptr(hist) if record_history else None
         row = 4 * _eng.COUNTER_WORDS
         self.mobility_history = []
@@ -628,9 +641,8 @@ class Context:
                 flush()
         flush()
         if record_history:
-            if self.n_shards == 1 and not self.always_collective:
-                out = a.to_host(hist).reshape(days, _eng.COUNTER_WORDS)
-                self._raise_on_problem(self.engine.read_counters())
+            if single:
+                out = self._history_to_host(hist, days)
             else:   # sharded: rows are summed over the shards when exported
                 out = self._reduce_counter_rows(hist, days)
                 self._raise_on_problem(self._read_counters_global())
