@@ -286,6 +286,7 @@ int reina_bind_buffers(reina_engine_t *e, const reina_buffers_t *b) {
 int reina_init_state(reina_engine_t *e, int32_t beds, int32_t icu, void *stream) {
     if (!e || !e->bound) return REINA_E_NOT_BOUND;
     hipStream_t s = (hipStream_t)stream;
+    e->init_beds = beds;
     hipLaunchKernelGGL(k_init, dim3(grid_for(e->cfg.n_agents, 256, 4096), 1), dim3(256), 0, s, e->d_ref, beds, icu);
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
@@ -294,6 +295,13 @@ int reina_init_state(reina_engine_t *e, int32_t beds, int32_t icu, void *stream)
 int reina_set_initial_state(reina_engine_t *e, const reina_initial_state_t *ic, void *stream) {
     if (!e || !ic) return REINA_E_INVALID;
     if (!e->bound) return REINA_E_NOT_BOUND;
+    if (e->cfg.n_shards <= 1 && ic->in_icu > 0 && ic->were_incubating > 0 && e->init_beds == 0) {
+        // (the reference raises AssertionError out of Context.__init__: an agent bound for ICU is refused a bed and
+        // Population.transfer_to_icu asserts state == HOSPITALIZED, main.pyx:1495 -> :350 -> :1603; a shard cannot tell --
+        // its own share of the beds may be 0 while the population has some -- and leaves the check to its caller)
+        g_last_error = "initial population condition: people in ICU but a hospital without beds (the reference refuses it)";
+        return REINA_E_INVALID;
+    }
     hipLaunchKernelGGL(k_initial_state, dim3(1, 1), dim3(PRO_THREADS), 0, (hipStream_t)stream, e->d_ref, *ic);
     HIP_CHECK(hipGetLastError());
     return REINA_OK;

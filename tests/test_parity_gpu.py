@@ -388,6 +388,22 @@ def test_initial_condition_with_more_slots_than_agents(n, ipc):
     _assert_state_equal(gpu, cpu)
 
 
+def test_the_hip_library_refuses_icu_patients_without_beds():
+    """the same precondition at libreina_hip.so's C ABI (tests/test_oracle_par.py has oracle B's): REINA_E_INVALID with a
+    message, nothing launched"""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=0, icu_units=2)
+    ctx = simulation.make_context(v, age_counts=datasets.scaled_population(5000), seed=1)
+    ic = eng.InitialState()
+    ic.incubating, ic.recovered_without_illness, ic.ill, ic.dead, ic.in_icu, ic.in_ward = 5, 5, 3, 1, 2, 0
+    ic.were_incubating, ic.confirmed_stride = 16, 1
+    with pytest.raises(eng.EngineError, match='without beds'):
+        ctx.engine.set_initial_state(ic)
+    ic.in_icu, ic.were_incubating = 0, 14
+    ctx.engine.set_initial_state(ic)
+    ctx.run(5)
+
+
 def test_large_bed_event_sets():
     """An unmitigated wave in 2.5 M agents with few beds: thousands of bed / ICU events per day
     while capacity binds, i.e. the counting-sort path of the event walk (more than 1024 ordered
