@@ -131,13 +131,15 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
         dist.barrier()
     torch.cuda.synchronize()
     gc.disable()
-    t0 = time.perf_counter()
-    hist = ctx.run(steps, record_history=True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    gc.enable()
+    try:   # (an exception out of the timed region must not leave the collector off for the workloads that follow)
+        t0 = time.perf_counter()
+        hist = ctx.run(steps, record_history=True)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t1 = time.perf_counter()
+    finally:
+        gc.enable()
     prof = ctx.engine.profile_read_kernels()
     ctx.engine.profile_enable(False)
     A = eng.MAX_AGES

@@ -98,16 +98,24 @@ enum {
     REINA_L_BEDS_OPEN, REINA_L_ICU_OPEN,                /* free beds / ICU units when the day opened (after new capacity was added) */
     REINA_L_EV_HOSPITALIZE, REINA_L_EV_TO_ICU,          /* the day's admission / ICU-transfer requests (counted by the stream): with the two words
                                                            above they say whether a resource can run out today, i.e. whether event ORDER matters */
+    REINA_L_WALK_TICKET,                                /* a large population's ordered event walk: the next priority bucket to be handed out
+                                                           (zeroed by the day's opening) */
     REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_NR = 48
 };
 
 /* The day's bed / ICU events are kept in buckets by priority range (buffers.hosp_events, 64-bit words):
  * R = REINA_HOSP_RANGES(n_agents) buckets of REINA_HOSP_BUCKET_CAP(n_agents, max_hosp_events) keys, preceded by
- * R / 2 words of bucket counts and 2 R words of per-bucket aggregates.  A population of at most
- * REINA_HOSP_SMALL_AGENTS agents has its events walked by one workgroup (at most REINA_MAX_HOSP_EVENTS - 1024 a day);
- * a larger one by one workgroup per bucket. */
+ * R / 2 words of bucket counts and 2 R words for the buckets' published saturating maps (the first R are used).  A
+ * population of at most REINA_HOSP_SMALL_AGENTS agents has its events walked by one workgroup (at most
+ * REINA_MAX_HOSP_EVENTS - 1024 a day); a larger one by one wave (or, for a bucket of more than 256 keys, one workgroup)
+ * per bucket inside the day's last launch.
+ * LIMIT: a bucket holds at most REINA_HOSP_MAX_BUCKET_KEYS keys, i.e. REINA_HOSP_BUCKET_CAP <= that: reina_create
+ * refuses a larger max_hosp_events.  With the usual max_hosp_events = n_agents / 128 that is reached at about 2.64e8
+ * agents per engine instance; above it pass REINA_HOSP_MAX_EVENTS_FOR(n_agents) (2 064 384 events a day: a day with
+ * more fails loudly, problem 103) or shard the population (reina_model_amd.engine.default_max_hosp_events does). */
 #define REINA_HOSP_MAX_RANGES 1024
+#define REINA_HOSP_MAX_BUCKET_KEYS 4096
 #define REINA_HOSP_SMALL_AGENTS (128u * REINA_MAX_HOSP_EVENTS)
 static inline uint32_t REINA_HOSP_RANGES(uint32_t n_agents) {
     uint32_t r = 16;
@@ -117,6 +125,9 @@ static inline uint32_t REINA_HOSP_RANGES(uint32_t n_agents) {
 static inline uint32_t REINA_HOSP_BUCKET_CAP(uint32_t n_agents, uint32_t max_hosp_events) {
     const uint32_t cap = max_hosp_events > REINA_MAX_HOSP_EVENTS ? max_hosp_events : REINA_MAX_HOSP_EVENTS;
     return 2u * (cap / REINA_HOSP_RANGES(n_agents)) + 64u;   /* twice the mean at the day capacity: > 10 sigma */
+}
+static inline uint32_t REINA_HOSP_MAX_EVENTS_FOR(uint32_t n_agents) {   /* the largest max_hosp_events reina_create accepts */
+    return ((REINA_HOSP_MAX_BUCKET_KEYS - 64u) / 2u) * REINA_HOSP_RANGES(n_agents);
 }
 static inline size_t REINA_HOSP_EVENT_WORDS(uint32_t n_agents, uint32_t max_hosp_events) {
     const size_t r = REINA_HOSP_RANGES(n_agents);

@@ -656,8 +656,10 @@ static int initial_target(Par *e, uint32_t slot, uint32_t k, uint32_t *t_out) {
 int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream) {
     (void)stream;
     if (!e->bound) return REINA_E_NOT_BOUND;
-    if (e->cfg.n_shards <= 1 && ic->in_icu > 0 && ic->were_incubating > 0 && SC(e, REINA_S_BEDS) == 0)
-        return REINA_E_INVALID;   /* the reference refuses people in ICU when the hospital has no beds (reina_hip.hip) */
+    if (e->cfg.n_shards <= 1 && ic->in_icu > 0 && SC(e, REINA_S_BEDS) == 0 &&
+        (uint64_t)ic->were_incubating > (uint64_t)ic->incubating + ic->recovered_without_illness + ic->ill + ic->dead)
+        return REINA_E_INVALID;   /* the reference refuses a walk that REACHES an ICU slot when the hospital has no beds
+                                     (main.pyx:1495 -> :350 -> :1603); a walk cut short before them constructs (:1456-1463) */
     const uint32_t M = ic->were_incubating;
     const uint32_t i_inc = ic->incubating, i_rec = i_inc + ic->recovered_without_illness, i_ill = i_rec + ic->ill,
                    i_dead = i_ill + ic->dead, i_icu = i_dead + ic->in_icu, i_ward = i_icu + ic->in_ward;

@@ -239,8 +239,9 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     while ((1u << e->h_params.hosp_range_bits) < e->h_params.hosp_ranges) e->h_params.hosp_range_bits++;
     e->h_params.hosp_bucket_cap = REINA_HOSP_BUCKET_CAP(cfg->n_agents, cfg->max_hosp_events);
     e->h_params.hosp_parallel = cfg->n_agents > REINA_HOSP_SMALL_AGENTS ? 1u : 0u;
-    if (e->h_params.hosp_parallel && e->h_params.hosp_bucket_cap > HOSP_P_THREADS * HOSP_P_E) {
-        g_last_error = "max_hosp_events too large for this population: a bucket of the event walk holds at most 4096 keys";
+    if (e->h_params.hosp_parallel && e->h_params.hosp_bucket_cap > REINA_HOSP_MAX_BUCKET_KEYS) {
+        g_last_error = "max_hosp_events too large for this population: a bucket of the event walk holds at most 4096 keys "
+                       "(pass at most REINA_HOSP_MAX_EVENTS_FOR(n_agents), include/reina_hip.h)";
         delete e;
         return REINA_E_INVALID;
     }
@@ -295,7 +296,10 @@ int reina_init_state(reina_engine_t *e, int32_t beds, int32_t icu, void *stream)
 int reina_set_initial_state(reina_engine_t *e, const reina_initial_state_t *ic, void *stream) {
     if (!e || !ic) return REINA_E_INVALID;
     if (!e->bound) return REINA_E_NOT_BOUND;
-    if (e->cfg.n_shards <= 1 && ic->in_icu > 0 && ic->were_incubating > 0 && e->init_beds == 0) {
+    // slot j of the walk over [0, were_incubating) is bound for ICU iff it lies behind the incubating / recovered / ill / dead
+    // slots: a walk that stops short of them (fewer recovered than incubating people, main.pyx:1456-1463) constructs
+    const uint64_t first_icu_slot = (uint64_t)ic->incubating + ic->recovered_without_illness + ic->ill + ic->dead;
+    if (e->cfg.n_shards <= 1 && ic->in_icu > 0 && (uint64_t)ic->were_incubating > first_icu_slot && e->init_beds == 0) {
         // (the reference raises AssertionError out of Context.__init__: an agent bound for ICU is refused a bed and
         // Population.transfer_to_icu asserts state == HOSPITALIZED, main.pyx:1495 -> :350 -> :1603; a shard cannot tell --
         // its own share of the beds may be 0 while the population has some -- and leaves the check to its caller)
@@ -419,14 +423,6 @@ static uint32_t day_blocks_for(uint32_t n_agents, uint32_t K, uint32_t n_cus) {
     return b;
 }
 
-// the ordered walk of a large population's bed / ICU events: one workgroup per priority bucket, two launches
-// (both return at once on a day on which no resource can run out)
-static void launch_parallel_walk(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, int today, hipStream_t s) {
-    const uint32_t R = e->h_params.hosp_ranges;
-    LAUNCH_TIMED(e, today, REINA_PK_HOSP_SORT, k_hosp_sort, dim3(R, K), dim3(HOSP_P_THREADS), 0, s, refs, dp);
-    LAUNCH_TIMED(e, today, REINA_PK_HOSP_WALK, k_hosp_walk, dim3(R, K), dim3(HOSP_P_THREADS), 0, s, refs, dp);
-}
-
 // One day's launches for K engine instances at once (K = 1: a single engine; K > 1: a group of
 // identically configured engines, one launch per phase for all of them, member = blockIdx.y).
 // `e` is the representative engine: geometry, scenario flags, optional second stream.
@@ -496,14 +492,23 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 2;
         const bool par = e->h_params.hosp_parallel != 0;
         if (par) {
-            // a large population: the events of a day on which order matters are walked by one workgroup per bucket
-            LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig, K), dim3(HOSP_THREADS), 0, s, refs, dp, scan_waves, scan_tiles,
-                         HI_INSTALL | HI_EVENTS);
-            launch_parallel_walk(e, refs, K, dp, today, s);
+            // a large population: the launch's first workgroups are the walkers of a day on which the events' order matters
+            // (one wave per priority bucket: R / 16 workgroups; they leave at once on any other day), the others install.
+            // One workgroup of 1024 threads per CU: all of them resident together, so the walk runs beside the installs.
+            const uint32_t n_walk = (e->h_params.hosp_ranges + 15u) / 16u;
+            int rest = (int)e->n_cus - (int)n_walk;
+            if (K > 1) rest = (int)(e->n_cus / K) - (int)n_walk;
+            if (rest > ig) rest = ig;
+            rest &= ~3;
+            if (rest < 4) rest = 4;
+            LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(n_walk + rest, K), dim3(HOSP_THREADS),
+                         (size_t)HOSP_P_THREADS * HOSP_P_E * 8, s, refs, dp, scan_waves, scan_tiles, HI_INSTALL | HI_EVENTS, n_walk);
         } else {
             // workgroup 0 walks the bed / ICU events of a day on which order matters, beside the installs
+            ig &= ~3;   // (four roles)
+            if (ig < 4) ig = K > 1 ? 2 : 4;
             LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig + 1, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
-                         refs, dp, scan_waves, scan_tiles, HI_HOSP_WG | HI_INSTALL | HI_EVENTS);
+                         refs, dp, scan_waves, scan_tiles, HI_HOSP_WG | HI_INSTALL | HI_EVENTS, 0u);
         }
     }
     HIP_CHECK(hipGetLastError());

@@ -128,13 +128,36 @@ class Day(ctypes.Structure):
                 ('history_row', ctypes.c_void_p)]
 
 
+HOSP_MAX_RANGES = 1024         # include/reina_hip.h: REINA_HOSP_MAX_RANGES
+HOSP_MAX_BUCKET_KEYS = 4096    # keys of one priority bucket the ordered event walk holds (k_hospital.inc: HOSP_P_THREADS * HOSP_P_E)
+
+
+def hosp_ranges(n_agents):
+    """include/reina_hip.h: REINA_HOSP_RANGES (priority buckets of the day's bed / ICU events)"""
+    r = 16
+    while r < HOSP_MAX_RANGES and r * 65536 < n_agents:
+        r <<= 1
+    return r
+
+
+def hosp_bucket_cap(n_agents, max_hosp_events):
+    """include/reina_hip.h: REINA_HOSP_BUCKET_CAP"""
+    return 2 * (max(MAX_HOSP_EVENTS, max_hosp_events) // hosp_ranges(n_agents)) + 64
+
+
+def default_max_hosp_events(n_agents):
+    """Bed / ICU events one day may hold: one agent in 128, but no more than the event walk's buckets can take (a bucket
+    holds at most HOSP_MAX_BUCKET_KEYS keys, sized for twice its mean share + 64; reina_create refuses more).  From about
+    2.6e8 agents per engine instance on, the day's capacity therefore stays at 2 064 384 events (0.8 % of the agents at
+    2.6e8, 0.1 % at 2e9) and a day with more fails loudly (problem 103) -- shard the population before that."""
+    per_bucket = (HOSP_MAX_BUCKET_KEYS - 64) // 2
+    return max(MAX_HOSP_EVENTS, min(n_agents // 128, per_bucket * hosp_ranges(n_agents)))
+
+
 def hosp_event_words(n_agents, max_hosp_events):
     """include/reina_hip.h: REINA_HOSP_EVENT_WORDS (64-bit words of buffers.hosp_events)"""
-    r = 16
-    while r < 1024 and r * 65536 < n_agents:
-        r <<= 1
-    cap = 2 * (max(MAX_HOSP_EVENTS, max_hosp_events) // r) + 64
-    return r // 2 + 2 * r + r * cap
+    r = hosp_ranges(n_agents)
+    return r // 2 + 2 * r + r * hosp_bucket_cap(n_agents, max_hosp_events)
 
 
 def bind_abi(lib, prefix):
@@ -208,7 +231,11 @@ class NumpyAllocator:
         return np.array(arr, copy=True)
 
 
-_PIN_SMALL = {}
+# short read-backs go through a small pinned block kept for the purpose -- one per host THREAD: the threaded ensemble
+# (ensemble.run_ensemble(batched=False)) reads members' histories back from several threads, each on its own stream,
+# and a block shared by all of them could be overwritten between one thread's synchronize() and its copy-out
+import threading
+_PIN_SMALL = threading.local()
 
 
 class TorchAllocator:
@@ -254,10 +281,13 @@ class TorchAllocator:
         if nbytes < (1 << 18) and t.dim() == 1:
             # short histories (a 20-day window is 146 KB) through ONE pinned block kept for the purpose: the pageable copy
             # of t.cpu() took 62 us of such a window's 820
-            key = t.dtype
-            pin = _PIN_SMALL.get(key)   # (one per process, not per Context: allocating pinned memory costs more than the copy)
+            blocks = getattr(_PIN_SMALL, 'blocks', None)   # (per thread, not per Context: allocating pinned memory costs more than the copy)
+            if blocks is None:
+                blocks = _PIN_SMALL.blocks = {}
+            key = (t.dtype, str(self.device))
+            pin = blocks.get(key)
             if pin is None:
-                pin = _PIN_SMALL[key] = self.torch.empty((1 << 18) // t.element_size(), dtype=t.dtype, pin_memory=True)
+                pin = blocks[key] = self.torch.empty((1 << 18) // t.element_size(), dtype=t.dtype, pin_memory=True)
             v = pin[:t.numel()]
             v.copy_(t, non_blocking=True)
             self.torch.cuda.current_stream(self.device).synchronize()

@@ -289,7 +289,7 @@ class Context:
         # overflow region of the same size (at most 2^20 records) for waves with more hits than agents
         cfg.max_candidates = total + 2 * (max(1024 * 1024, total // 2) if self.n_shards > 1 else 1024 * 1024)
         cfg.max_queue = total + 64
-        cfg.max_hosp_events = max(_eng.MAX_HOSP_EVENTS, total // 128)   # bed / ICU events of one day
+        cfg.max_hosp_events = _eng.default_max_hosp_events(total)   # bed / ICU events of one day (clamped to what the walk's buckets hold)
         cfg.n_shards = self.n_shards
         cfg.shard_rank = self.shard_rank
         slots = 64

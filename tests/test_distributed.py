@@ -28,9 +28,11 @@ def _launch(world, backend, days, total, timeout=600, extra_env=None, mode=None)
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_gloo_sharded_run_equals_in_process_sharded_run(world):
-    r = _launch(world, 'gloo', 100, 40000)
+    """world 8 = the rank count of BASELINE configs[3] (one process per GPU of the node): eight ranks' pressure blocks
+    through one all-reduce per day, beds / ICU units / imports split eight ways"""
+    r = _launch(world, 'gloo', 100 if world < 8 else 70, 40000, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'DIST_OK world=%d' % world in r.stdout
 

@@ -323,5 +323,9 @@ def test_the_abi_refuses_icu_patients_without_beds():
     ic.were_incubating, ic.confirmed_stride = 16, 1
     with pytest.raises(eng.EngineError):
         ctx.engine.set_initial_state(ic)
+    # a walk that stops short of the ICU slots (raw numbers with fewer recovered than incubating people: the reference walks
+    # range(were_incubating()) and never reaches them, main.pyx:1456-1463) is a configuration the reference constructs
+    ic.in_icu, ic.were_incubating = 2, 12
+    ctx.engine.set_initial_state(ic)
     ic.in_icu, ic.were_incubating = 0, 14
     ctx.engine.set_initial_state(ic)

@@ -340,6 +340,20 @@ def test_run_ensemble_batched_equals_threaded():
     assert np.array_equal(a, b)
 
 
+def test_threaded_ensemble_short_histories_do_not_share_a_pinned_block():
+    """A history of 34 days or fewer comes back through the small pinned block of TorchAllocator.to_host; the threaded
+    ensemble reads back from several host threads at once, so that block must be per thread (round-2 advisor finding:
+    with one block per process, members' short histories could be swapped or corrupted)."""
+    from reina_model_amd import ensemble
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=12, icu_units=2)
+    ages = datasets.scaled_population(30000)
+    a = ensemble.run_ensemble(v, range(16), 20, age_counts=ages, batched=True)
+    for _ in range(3):
+        b = ensemble.run_ensemble(v, range(16), 20, age_counts=ages, batched=False, threads=8)
+        assert np.array_equal(a, b)
+
+
 IPC = dict(dead=30, in_icu=12, in_ward=20, confirmed_cases=230, incubating=200, ill=150, recovered=900)
 
 
@@ -399,6 +413,10 @@ def test_the_hip_library_refuses_icu_patients_without_beds():
     ic.were_incubating, ic.confirmed_stride = 16, 1
     with pytest.raises(eng.EngineError, match='without beds'):
         ctx.engine.set_initial_state(ic)
+    # a walk that stops short of the ICU slots (raw numbers with fewer recovered than incubating people: the reference walks
+    # range(were_incubating()) and never reaches them, main.pyx:1456-1463) is a configuration the reference constructs
+    ic.in_icu, ic.were_incubating = 2, 12
+    ctx.engine.set_initial_state(ic)
     ic.in_icu, ic.were_incubating = 0, 14
     ctx.engine.set_initial_state(ic)
     ctx.run(5)
