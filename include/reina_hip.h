@@ -386,6 +386,16 @@ int reina_build_contact_tables(const double *base, const int32_t *row_page, cons
                                const double *mobility, uint32_t n_mobility, const int32_t *rows_mat,
                                const int32_t *sorted_mat, uint32_t n_ages, uint32_t n_entries, double *totals_out,
                                double *cum_out, float *nrc_out, uint32_t *thr_out, uint32_t thr_stride);
+/* TEST HOOK, no reference counterpart: evaluates one numeric primitive of the day step (csrc/reina_prims.h) for n input
+ * records ON THE DEVICE, one lane per record, so that the device build of Philox4x32 / Philox2x32 / inverse normal / exp /
+ * log / gamma / the contact-count draw can be checked against published known answers and against the host build bit for
+ * bit (tests/test_prims_gpu.py).  Host pointers, synchronous.  Words per record (in -> out): REINA_TP_PHILOX4 (k0, k1, c0,
+ * c1, c2, c3) -> 4; REINA_TP_PHILOX2 (key, c0, c1) -> 2; REINA_TP_NORMAL (32-bit draw) -> float bits; REINA_TP_EXPF /
+ * REINA_TP_LOGF (float bits) -> float bits; REINA_TP_GAMMA (mu bits, cv bits, k0, k1, who, day, purpose, first block) ->
+ * float bits; REINA_TP_COUNT_DRAW (k0, k1, who, day) -> the 32-bit word the contact count is inverted from. */
+enum { REINA_TP_PHILOX4 = 0, REINA_TP_PHILOX2, REINA_TP_NORMAL, REINA_TP_EXPF, REINA_TP_LOGF, REINA_TP_GAMMA, REINA_TP_COUNT_DRAW,
+       REINA_TP_NR };
+int reina_test_prims(int what, const uint32_t *in_host, uint32_t n, uint32_t *out_host);
 const char *reina_last_error(void);
 int reina_abi_version(void);
 

@@ -39,6 +39,7 @@ typedef struct {
     uint32_t n_ranges;
     int32_t range_min[REINA_MAX_RANGES], range_max[REINA_MAX_RANGES];
     float psus_max[REINA_MAX_VARIANTS];
+    uint32_t cthr[REINA_MAX_AGES][REINA_COUNT_WORDS];   /* contact-count thresholds of every age (reina_contacts.h) */
     reina_allreduce_fn coll_fn;
     void *coll_comm;
 } Par;
@@ -159,6 +160,7 @@ int par_upload_contact_tables(Par *e, const reina_contact_tables_t *t, void *str
     e->n_ranges = t->n_ranges;
     memcpy(e->range_min, t->range_min, sizeof(e->range_min));
     memcpy(e->range_max, t->range_max, sizeof(e->range_max));
+    for (uint32_t a = 0; a < A; a++) rc_count_thresholds(e->nrc[a], e->cthr[a]);
     return 0;
 }
 
@@ -495,18 +497,10 @@ static void run_scan(Par *e, const reina_day_t *dp) {
                 int dayrel = st == RS_INCUBATION ? -(int)dl : (int)RH_DOI(w, dp->day);
                 float inf = (dayrel >= -10 && dayrel <= 10) ? d->infectiousness_over_time[v][dayrel + 10] : 0.0f;
                 if (inf != 0.0f) {
-                    float factor = 1.0f;
-                    int limit = 100;
-                    if (st == RS_ILLNESS && sev != RV_ASYMPTOMATIC) {
-                        factor = 0.5f;
-                        limit = 5;
-                    }
-                    float z = rp_normal_from_u32(rp_philox(e->k0, e->k1, i, dp->day, RP_P_NRCONTACTS, 0).v[0]);
-                    float f = rp_expf(0.5f * z) * e->nrc[age];
-                    f *= factor;
-                    if (f < 1.0f) f = 1.0f;
-                    nr = (int)f - 1;
-                    if (nr > limit) nr = limit;
+                    /* get_nr_contacts (main.pyx:1308-1320) by inversion of the day's draw through the count thresholds
+                     * of the agent's age; an agent with symptoms draws from the (factor 0.5, limit 5) class */
+                    nr = rc_count_from_draw(e->cthr[age], st == RS_ILLNESS && sev != RV_ASYMPTOMATIC,
+                                            rp_count_draw(e->k0, e->k1, i, dp->day));
                     if (nr > 0) {
                         float src_inf = inf;
                         if (sev == RV_ASYMPTOMATIC) src_inf *= d->p_asymptomatic_infection[v];
@@ -1079,6 +1073,15 @@ int par_profile_read_kernels(Par *e, double *ms, uint64_t *n) {
 }
 const char *par_last_error(void) { return ""; }
 
+/* the ABI's test hook on the host build of the primitives (include/reina_hip.h: reina_test_prims) */
+int par_test_prims(int what, const uint32_t *in, uint32_t n, uint32_t *out) {
+    uint32_t n_in = 0, n_out = 0;
+    rp_test_prim_words(what, &n_in, &n_out);
+    if (!n_in || !in || !out) return REINA_E_INVALID;
+    for (uint32_t k = 0; k < n; k++) rp_test_prim(what, in + (size_t)k * n_in, out + (size_t)k * n_out);
+    return 0;
+}
+
 /* ---- primitive test hooks (checked against scipy / known answers in tests/test_prims.py) ---- */
 void par_test_philox(const uint32_t *key, const uint32_t *ctr, uint32_t *out) {
     rp_u4 r = rp_philox(key[0], key[1], ctr[0], ctr[1], ctr[2], ctr[3]);
@@ -1096,13 +1099,9 @@ void par_test_gamma(float mu, float cv, uint64_t seed, uint32_t day, uint32_t pu
         y[i] = rp_gamma_mu_cv(mu, cv, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, day, purpose, 1);
 }
 void par_test_nr_contacts(uint64_t seed, uint32_t day, float nrc, float factor, int limit, int32_t *y, int n) {
-    for (int i = 0; i < n; i++) {
-        float z = rp_normal_from_u32(rp_philox((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, day, RP_P_NRCONTACTS, 0).v[0]);
-        float f = rp_expf(0.5f * z) * nrc;
-        f *= factor;
-        if (f < 1.0f) f = 1.0f;
-        int nr = (int)f - 1;
-        if (nr > limit) nr = limit;
-        y[i] = nr;
-    }
+    uint32_t row[REINA_COUNT_WORDS];
+    (void)limit;
+    rc_count_thresholds(nrc, row);
+    for (int i = 0; i < n; i++)
+        y[i] = rc_count_from_draw(row, factor < 1.0f, rp_count_draw((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, day));
 }

@@ -15,6 +15,42 @@
 #include <stdlib.h>
 #include <string.h>
 
+// ------------------------------------------------------------------ the contact COUNT of an infectious agent
+// get_nr_contacts (main.pyx:1308-1320): f = lognormal(0, 0.5) * nr_contacts_by_age[age] * factor; f = max(f, 1);
+// nr = min(int(f) - 1, limit) -- (factor, limit) = (1, 100), or (0.5, 5) for an agent with symptoms.  The parallel engines
+// draw it by INVERSION from one 32-bit word r (cell centre u = (r + 0.5) / 2^32 of the uniform): nr > k iff
+// exp(z / 2) * c >= k + 2 iff u >= Phi(2 ln((k + 2) / c)), c = nr_contacts_by_age * factor -- so a row of `limit`
+// thresholds thr[k] = the smallest r with nr > k turns the draw into a table search (no inverse normal, no exp on
+// the device: they were 650 + 130 SIMD cycles per 64 agents, a fifth of k_day on a peak day).  Built on the host in
+// double whenever the contact tables are (re)built; the HIP library and the CPU oracle call this same function.
+#define REINA_COUNT_FULL 100   // limit of an agent without symptoms
+#define REINA_COUNT_ILL 5      // limit of an agent with symptoms (factor 0.5)
+#define REINA_COUNT_WORDS 112  // one row: [0, 100) full class, [100, 105) ill class, padding to a multiple of 16 bytes
+static inline void rc_count_thresholds(float nr_contacts_of_age, uint32_t *row /* [REINA_COUNT_WORDS] */) {
+    for (int cls = 0; cls < 2; cls++) {
+        const double c = (double)nr_contacts_of_age * (cls ? 0.5 : 1.0);
+        const int limit = cls ? REINA_COUNT_ILL : REINA_COUNT_FULL;
+        uint32_t *thr = row + (cls ? REINA_COUNT_FULL : 0);
+        for (int k = 0; k < limit; k++) {
+            double t = 4294967296.0;
+            if (c > 0.0) {
+                const double x = 2.0 * log((double)(k + 2) / c);             // z from which exp(z / 2) * c >= k + 2
+                t = ceil(4294967296.0 * (0.5 * erfc(-x / sqrt(2.0))) - 0.5);   // the first cell whose centre lies at or above Phi(x)
+            }
+            thr[k] = t <= 0.0 ? 0u : t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+        }
+    }
+    for (int k = REINA_COUNT_FULL + REINA_COUNT_ILL; k < REINA_COUNT_WORDS; k++) row[k] = 0xFFFFFFFFu;
+}
+// the count a draw gives with such a row (plain form: the oracle, Context.sample; the kernels start from a guide table)
+static inline int rc_count_from_draw(const uint32_t *row, int ill, uint32_t r) {
+    const uint32_t *thr = row + (ill ? REINA_COUNT_FULL : 0);
+    const int limit = ill ? REINA_COUNT_ILL : REINA_COUNT_FULL;
+    int n = 0;
+    while (n < limit && r >= thr[n]) n++;
+    return n;
+}
+
 static int reina_build_contact_tables_impl(const double *base, const int32_t *row_page, const int32_t *row_place,
                                            uint32_t n_rows, const double *mobility, uint32_t n_mobility,
                                            const int32_t *rows_mat, const int32_t *sorted_mat, uint32_t A, uint32_t E,

@@ -146,6 +146,12 @@ extern "C" {
 
 int reina_abi_version(void) { return 2; }
 
+#ifdef REINA_ABLATE
+int reina_debug_ablate(uint32_t bits) {   // diagnostic builds only (tools/ablate_day.py)
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ablate_dev), &bits, sizeof(bits)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int reina_build_contact_tables(const double *base, const int32_t *row_page, const int32_t *row_place, uint32_t n_rows,
                                const double *mobility, uint32_t n_mobility, const int32_t *rows_mat,
                                const int32_t *sorted_mat, uint32_t n_ages, uint32_t n_entries, double *totals_out,
@@ -153,6 +159,34 @@ int reina_build_contact_tables(const double *base, const int32_t *row_page, cons
     const int rc = reina_build_contact_tables_impl(base, row_page, row_place, n_rows, mobility, n_mobility, rows_mat, sorted_mat,
                                                    n_ages, n_entries, totals_out, cum_out, nrc_out, thr_out, thr_stride);
     return rc == 0 ? REINA_OK : REINA_E_INVALID;
+}
+
+// test hook: one primitive of reina_prims.h evaluated on the device, one lane per record
+__global__ __launch_bounds__(256) void k_test_prims(int what, const uint32_t *in, uint32_t n, uint32_t n_in, uint32_t n_out, uint32_t *out) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < n_in; j++) a[j] = in[(size_t)k * n_in + j];
+        rp_test_prim(what, a, o);
+        for (uint32_t j = 0; j < n_out; j++) out[(size_t)k * n_out + j] = o[j];
+    }
+}
+
+int reina_test_prims(int what, const uint32_t *in_host, uint32_t n, uint32_t *out_host) {
+    uint32_t n_in = 0, n_out = 0;
+    rp_test_prim_words(what, &n_in, &n_out);
+    if (!n_in || !in_host || !out_host) return REINA_E_INVALID;
+    if (n == 0) return REINA_OK;
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    HIP_CHECK(hipMalloc(&d_in, (size_t)n * n_in * 4));
+    HIP_CHECK_OR(hipMalloc(&d_out, (size_t)n * n_out * 4), (void)hipFree(d_in));
+#define TP_CLEAN { (void)hipFree(d_in); (void)hipFree(d_out); }
+    HIP_CHECK_OR(hipMemcpy(d_in, in_host, (size_t)n * n_in * 4, hipMemcpyHostToDevice), TP_CLEAN);
+    hipLaunchKernelGGL(k_test_prims, dim3(grid_for(n, 256, 4096)), dim3(256), 0, nullptr, what, d_in, n, n_in, n_out, d_out);
+    HIP_CHECK_OR(hipGetLastError(), TP_CLEAN);
+    HIP_CHECK_OR(hipMemcpy(out_host, d_out, (size_t)n * n_out * 4, hipMemcpyDeviceToHost), TP_CLEAN);
+    TP_CLEAN;
+#undef TP_CLEAN
+    return REINA_OK;
 }
 
 int reina_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,
@@ -251,7 +285,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK_OR(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice), free_engine(e));
     HIP_CHECK_OR(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice), free_engine(e));
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)day_shared_bytes(REINA_LDS_ROWS, REINA_MAX_SHARDS)), free_engine(e));
+                                     (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)((size_t)REINA_MAX_HOSP_EVENTS * 8)), free_engine(e));
     *out = e;
@@ -359,6 +393,26 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
             T.row_of_age[a] = (uint8_t)r;
         }
         T.n_rows = n_rows;
+        // contact-count thresholds: one row per distinct nr_contacts_by_age value
+        uint32_t n_crows = 0;
+        float crow_value[REINA_MAX_AGES];
+        for (uint32_t a = 0; a < A; a++) {
+            uint32_t r = 0;
+            for (; r < n_crows; r++)
+                if (std::memcmp(&crow_value[r], &t->nr_contacts_by_age[a], sizeof(float)) == 0) break;
+            if (r == n_crows) {
+                crow_value[r] = t->nr_contacts_by_age[a];
+                rc_count_thresholds(crow_value[r], T.cthr[r]);
+                int idx = 0;
+                for (uint32_t b = 0; b < 256; b++) {
+                    while (idx < REINA_COUNT_FULL && T.cthr[r][idx] <= (b << 24)) idx++;   // thresholds are non-decreasing
+                    T.cguide[r][b] = (uint8_t)idx;
+                }
+                n_crows++;
+            }
+            T.crow_of_age[a] = (uint8_t)r;
+        }
+        T.n_crows = n_crows;
         // coarse index -> age map (the age of a sampled target: one table read + 0-1 steps instead of a search)
         uint32_t shift = 0;
         while (((uint64_t)e->cfg.n_agents >> shift) >= REINA_AGE_BLOCKS) shift++;
@@ -454,6 +508,8 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     const uint32_t day_blocks = day_blocks_for(N, K, e->n_cus);
     uint32_t lds_rows = K > 1 ? e->group_lds_rows : e->h_tables.n_rows;   // (a member stages min(its own rows, lds_rows))
     if (lds_rows > REINA_LDS_ROWS) lds_rows = REINA_LDS_ROWS;
+    uint32_t lds_crows = K > 1 ? e->group_lds_crows : e->h_tables.n_crows;
+    if (lds_crows > REINA_LDS_CROWS) lds_crows = REINA_LDS_CROWS;
     {
         const int g = 2 + tg;
         if (!e->testing_ever) {
@@ -469,8 +525,8 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         // a vaccination programme: its pass over the agents comes after the test queue and before the stream
         // (HealthcareSystem.iterate, main.pyx:514-558)
         if (dp.n_vaccinations) LAUNCH_TIMED(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
-        LAUNCH_TIMED(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, e->cfg.n_shards), s,
-                     refs, dp, lds_rows);
+        LAUNCH_TIMED(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s,
+                     refs, dp, lds_rows, lds_crows);
     }
     e->cur_scan_waves = day_blocks * DAY_WAVES;   // (the day's later launches walk the per-wave slices)
     (void)scan_tiles;
@@ -661,9 +717,11 @@ int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_d
     HIP_CHECK(hipMemcpyAsync(g->d_refs, g->h_refs.data(), sizeof(MemberRef) * K, hipMemcpyHostToDevice, s));
     reina_engine_t *e0 = g->members[0];
     bool tested = false;  // the test-queue kernels run for all members once any member ever tested
-    e0->group_lds_rows = 0;
-    for (auto m : g->members)
+    e0->group_lds_rows = e0->group_lds_crows = 0;
+    for (auto m : g->members) {
         if (m->h_tables.n_rows > e0->group_lds_rows) e0->group_lds_rows = m->h_tables.n_rows;
+        if (m->h_tables.n_crows > e0->group_lds_crows) e0->group_lds_crows = m->h_tables.n_crows;
+    }
     for (auto m : g->members) tested = tested || m->testing_ever;
     for (uint32_t d = 0; d < n_days; d++) tested = tested || days[d].testing_mode != RT_NO_TESTING;
     e0->testing_ever = e0->testing_ever || (tested && n_days == 0);

@@ -86,10 +86,16 @@ RP_HD rp_u2 rp_philox2(uint32_t key, uint32_t c0, uint32_t c1) {
 RP_HD uint32_t rp_contact_key(uint32_t k0, uint32_t k1) { return k0 ^ (k1 * 0x9E3779B9u + 0x7F4A7C15u); }
 RP_HD uint32_t rp_contact_ctr(uint32_t day, uint32_t c, uint32_t half) { return (day & 0xFFFu) | (c << 12) | (half << 20); }
 
+// the draw behind an infectious agent's contact COUNT of the day (inverted through the count thresholds,
+// reina_contacts.h: rc_count_thresholds): its own key, counter (agent, day)
+RP_HD uint32_t rp_count_draw(uint32_t k0, uint32_t k1, uint32_t who, uint32_t day) {
+    return rp_philox2(rp_contact_key(k0, k1) ^ 0x6A09E667u, who, day).v[0];
+}
+
 // Purposes (counter word c2 low byte). The sub-index (contact number, import try, tracer id)
 // goes in c3 or the upper bits of c2; `who` (agent / event id) in c0, day in c1.
 enum {
-    RP_P_NRCONTACTS = 1,  // (agent, day): v[0] normal for the lognormal contact count
+    RP_P_NRCONTACTS = 1,  // (unused since the contact count is drawn by inversion: rp_count_draw)
     RP_P_CONTACT = 2,     // (unused since the contact draws moved to Philox2x32: rp_contact_key / rp_contact_ctr)
     RP_P_INFECT = 3,      // (target, day, c3 = block): severity, incubation gamma
     RP_P_ONSET = 4,       // (agent, day, c3 = block): onset->removed gamma; block 0 v[3] = "tested anyway"
@@ -345,5 +351,33 @@ RP_HD int32_t rp_capacity_share(const int32_t *words, uint32_t n_shards, uint32_
 #define RP_MIRROR_PROBES 16u      // probes per cell of the mirror table (tables are kept >= ~40 % full)
 #define RP_MIRROR_MIN_SLOTS 8u    // smallest table: fully scanned by one lookup
 #define RP_MIRROR_STALE_DAYS 14u   // a stand-in infector may be an agent that aimed at another shard up to this many days ago
+
+// ------------------------------------------------------------------ test hook (reina_test_prims / par_test_prims)
+// One record of one primitive, the same code path on a CDNA4 lane and on a host core: what the device-side known-answer
+// tests evaluate (include/reina_hip.h: REINA_TP_*).  Words per record: rp_test_prim_words.
+RP_HD void rp_test_prim_words(int what, uint32_t *n_in, uint32_t *n_out) {
+    const uint32_t in_w[7] = {6, 3, 1, 1, 1, 8, 4}, out_w[7] = {4, 2, 1, 1, 1, 1, 1};
+    *n_in = (what >= 0 && what < 7) ? in_w[what] : 0u;
+    *n_out = (what >= 0 && what < 7) ? out_w[what] : 0u;
+}
+RP_HD void rp_test_prim(int what, const uint32_t *in, uint32_t *out) {
+    if (what == 0) {          // Philox4x32-10: (k0, k1, c0, c1, c2, c3) -> 4 words
+        const rp_u4 r = rp_philox(in[0], in[1], in[2], in[3], in[4], in[5]);
+        out[0] = r.v[0]; out[1] = r.v[1]; out[2] = r.v[2]; out[3] = r.v[3];
+    } else if (what == 1) {   // Philox2x32-10: (key, c0, c1) -> 2 words
+        const rp_u2 r = rp_philox2(in[0], in[1], in[2]);
+        out[0] = r.v[0]; out[1] = r.v[1];
+    } else if (what == 2) {   // inverse normal of a 32-bit draw -> float bits
+        out[0] = rp_f2u(rp_normal_from_u32(in[0]));
+    } else if (what == 3) {
+        out[0] = rp_f2u(rp_expf(rp_u2f(in[0])));
+    } else if (what == 4) {
+        out[0] = rp_f2u(rp_logf(rp_u2f(in[0])));
+    } else if (what == 5) {   // gamma(mu, cv): (mu bits, cv bits, k0, k1, who, day, purpose, first block) -> float bits
+        out[0] = rp_f2u(rp_gamma_mu_cv(rp_u2f(in[0]), rp_u2f(in[1]), in[2], in[3], in[4], in[5], in[6], in[7]));
+    } else if (what == 6) {   // the draw behind the contact count: (k0, k1, who, day) -> 32-bit word
+        out[0] = rp_count_draw(in[0], in[1], in[2], in[3]);
+    }
+}
 
 #endif  // REINA_PRIMS_H

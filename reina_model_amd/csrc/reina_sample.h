@@ -6,6 +6,7 @@
 
 #include "../../include/reina_hip.h"
 #include "reina_prims.h"
+#include "reina_contacts.h"
 
 enum {
     REINA_SAMPLE_CONTACTS_PER_DAY = 0, REINA_SAMPLE_SYMPTOM_SEVERITY, REINA_SAMPLE_INCUBATION_PERIOD,
@@ -38,15 +39,12 @@ static inline int reina_sample_impl(const reina_disease_t *d, uint64_t seed, int
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const int sev = severity >= 0 ? severity : RV_MILD;
     const uint32_t day = 0xFFFFFF00u + (uint32_t)what;  // a "day" no simulation reaches
+    uint32_t count_row[REINA_COUNT_WORDS];
+    if (what == REINA_SAMPLE_CONTACTS_PER_DAY) rc_count_thresholds(nrc, count_row);
     for (int i = 0; i < n; i++) {
         const uint32_t who = (uint32_t)i;
         if (what == REINA_SAMPLE_CONTACTS_PER_DAY) {
-            float z = rp_normal_from_u32(rp_philox(k0, k1, who, day, RP_P_NRCONTACTS, 0).v[0]);
-            float f = rp_expf(0.5f * z) * nrc;
-            if (f < 1.0f) f = 1.0f;
-            int nr = (int)f - 1;
-            if (nr > 100) nr = 100;
-            out[i] = nr;
+            out[i] = rc_count_from_draw(count_row, 0, rp_count_draw(k0, k1, who, day));   // the engine's own count sampler
         } else if (what == REINA_SAMPLE_SYMPTOM_SEVERITY) {
             out[i] = rs_severity(d, age, rp_uniform24(rp_philox(k0, k1, who, day, RP_P_INFECT, 0).v[0]));
         } else if (what == REINA_SAMPLE_INCUBATION_PERIOD) {

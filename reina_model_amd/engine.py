@@ -52,7 +52,9 @@ ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial
                  'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
                  'profile_read_kernels',
                  'group_create', 'group_destroy', 'group_upload_contact_tables', 'group_run_days',
-                 'build_contact_tables', 'last_error', 'abi_version')
+                 'build_contact_tables', 'test_prims', 'last_error', 'abi_version')
+TEST_PRIMS = dict(philox4=(0, 6, 4), philox2=(1, 3, 2), normal=(2, 1, 1), expf=(3, 1, 1), logf=(4, 1, 1), gamma=(5, 8, 1),
+                  count_draw=(6, 4, 1))   # name -> (REINA_TP_*, words in, words out)
 
 
 class Config(ctypes.Structure):
@@ -187,6 +189,7 @@ def bind_abi(lib, prefix):
                             ctypes.c_float, ctypes.c_int, vp]
     f['build_contact_tables'].argtypes = [vp, vp, vp, ctypes.c_uint32, vp, ctypes.c_uint32, vp, vp, ctypes.c_uint32,
                                           ctypes.c_uint32, vp, vp, vp, vp, ctypes.c_uint32]
+    f['test_prims'].argtypes = [ctypes.c_int, vp, ctypes.c_uint32, vp]
     f['profile_enable'].argtypes = [vp, ctypes.c_int]
     f['profile_read'].argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                                   ctypes.POINTER(ctypes.c_double)]
@@ -492,6 +495,19 @@ def load_hip_library():
                               'there is no CPU fallback' % HIP_LIB_PATH)
         _hip_lib = ctypes.CDLL(HIP_LIB_PATH)
     return _hip_lib
+
+
+def test_prims(f, name, records):
+    """TEST HOOK (include/reina_hip.h: reina_test_prims): evaluates primitive `name` for every row of `records` (uint32
+    words) with the bound library `f` (bind_abi) -- on the device for the HIP library, one lane per record."""
+    what, n_in, n_out = TEST_PRIMS[name]
+    rec = np.ascontiguousarray(np.asarray(records, dtype=np.uint32).reshape(-1, n_in))
+    out = np.zeros((len(rec), n_out), dtype=np.uint32)
+    rc = f['test_prims'](what, rec.ctypes.data, len(rec), out.ctypes.data)
+    if rc != 0:
+        msg = f['last_error']()
+        raise EngineError('test_prims failed (%d): %s' % (rc, msg.decode() if msg else ''))
+    return out
 
 
 def hip_engine(config, disease, device='cuda:0'):

@@ -55,6 +55,21 @@ def test_philox2x32_10_known_answers(L):
     assert ph(0x13198a2e, [0x243f6a88, 0x85a308d3]) == [0xdd7ce038, 0xf62a4c12]
 
 
+def test_the_abi_test_hook_evaluates_the_same_primitives():
+    """include/reina_hip.h: reina_test_prims, host build (par_test_prims) -- the device build answers the same records in
+    tests/test_prims_gpu.py"""
+    from reina_model_amd import engine as eng
+    f = eng.bind_abi(par_backend.lib(), 'par_')
+    assert [int(x) for x in eng.test_prims(f, 'philox4', [[0xa4093822, 0x299f31d0, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]])[0]] == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert [int(x) for x in eng.test_prims(f, 'philox2', [[0x13198a2e, 0x243f6a88, 0x85a308d3]])[0]] == [0xdd7ce038, 0xf62a4c12]
+    x = np.linspace(-5, 5, 1001).astype(np.float32)
+    y = eng.test_prims(f, 'expf', x.view(np.uint32))[:, 0].view(np.float32)
+    assert np.max(np.abs(y - np.exp(x.astype(np.float64))) / np.exp(x.astype(np.float64))) < 2e-7
+    bad = np.zeros(4, dtype=np.uint32)
+    assert f['test_prims'](99, bad.ctypes.data, 1, bad.ctypes.data) != 0   # unknown primitive: refused
+
+
 def test_expf_logf_accuracy(L):
     x = np.linspace(-20, 20, 400001).astype(np.float32)
     y = np.zeros_like(x)
