@@ -203,16 +203,28 @@ typedef struct {
     int32_t range_max[REINA_MAX_RANGES];
 } reina_contact_tables_t;
 
+/* Everything about an agent that is touched only at EVENTS (infection, onset, hospital, tracing), one 32-byte record =
+ * one HBM sector per agent (the reference keeps the same fields in its Person struct, main.pyx:132-144).  Round 2 kept
+ * them in seven arrays: installing one infection touched five sectors of the target and two of the source. */
+typedef struct {
+    uint64_t claim;           /* winner-selection key of the day's exposures, init 0xFF..FF; [4095-day:12][priority:20][id:32] */
+    int32_t infector;         /* Person.infector, -1 = none */
+    int32_t n_infected;       /* Person.other_people_infected */
+    float onset_days;         /* Person.days_from_onset_to_removed */
+    int32_t vacc_day;         /* Person.day_of_vaccination, -1 = never */
+    int32_t first_infectee;   /* infectees beyond the REINA_INLINE_INFECTEES inline slots: head of a linked list, -1 = empty */
+    int32_t next_sibling;     /* ... and its link: next such infectee of the same infector, -1 = end */
+} reina_cold_t;
+/* Person.infectees (main.pyx:128,231: 64 ids per person, kept while contact tracing is on): the first
+ * REINA_INLINE_INFECTEES of an agent's infectees sit side by side in buffers.infectees (slot = their rank among the
+ * agent's infections, -1 = empty), so contact tracing reads them in one access; the rest go to the linked list above. */
+#define REINA_INLINE_INFECTEES 8
+
 /* Per-agent state and work lists: device pointers owned by the caller. */
 typedef struct {
     uint32_t *hot;            /* [N] packed hot word, layout in reina_prims.h */
-    int32_t *infector;        /* [N] Person.infector, -1 = none */
-    int32_t *n_infected;      /* [N] Person.other_people_infected */
-    float *onset_days;        /* [N] Person.days_from_onset_to_removed */
-    int32_t *vacc_day;        /* [N] Person.day_of_vaccination, -1 = never */
-    int32_t *first_infectee;  /* [N] head of the infectee list (Person.infectees), -1 = empty */
-    int32_t *next_sibling;    /* [N] next infectee of the same infector, -1 = end */
-    uint64_t *claim;          /* [N] winner-selection keys, init 0xFF..FF */
+    reina_cold_t *cold;       /* [N] event-time fields */
+    int32_t *infectees;       /* [N * REINA_INLINE_INFECTEES] inline infectee slots */
     int32_t *counters;        /* [REINA_COUNTER_WORDS] */
     int32_t *control;         /* [REINA_L_NR] */
     uint32_t *work_items;     /* [max_work_items * 4]: the second half holds the per-slice lists of symptom onsets

@@ -67,7 +67,7 @@ static int age_of(const Par *e, uint32_t i) {
     return lo;
 }
 
-int par_abi_version(void) { return 2; }
+int par_abi_version(void) { return 3; }
 
 /* Context.sample: the shared host-side sampler (utility, not part of the day step) */
 int par_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,
@@ -124,13 +124,14 @@ int par_init_state(Par *e, int32_t beds, int32_t icu, void *stream) {
     uint32_t N = e->cfg.n_agents;
     for (uint32_t i = 0; i < N; i++) {
         e->buf.hot[i] = 0;
-        e->buf.infector[i] = -1;
-        e->buf.n_infected[i] = 0;
-        e->buf.onset_days[i] = 0.0f;
-        e->buf.vacc_day[i] = -1;
-        e->buf.first_infectee[i] = -1;
-        e->buf.next_sibling[i] = -1;
-        e->buf.claim[i] = ~0ull;
+        e->buf.cold[i].infector = -1;
+        e->buf.cold[i].n_infected = 0;
+        e->buf.cold[i].onset_days = 0.0f;
+        e->buf.cold[i].vacc_day = -1;
+        e->buf.cold[i].first_infectee = -1;
+        e->buf.cold[i].next_sibling = -1;
+        e->buf.cold[i].claim = ~0ull;
+        for (int k = 0; k < REINA_INLINE_INFECTEES; k++) e->buf.infectees[(size_t)i * REINA_INLINE_INFECTEES + k] = -1;
     }
     if (e->cfg.n_shards > 1)
         for (size_t k = 0; k < (size_t)REINA_MAX_RANGES * REINA_MAX_VARIANTS * e->cfg.mirror_slots; k++)
@@ -211,7 +212,7 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
     rp_u4 r = rp_philox(e->k0, e->k1, t, day, RP_P_INFECT, 0);
     float val = rp_uniform24(r.v[0]);
     float vmod = 1.0f;
-    if ((w & RH_VACCINATED) && ((int)day - e->buf.vacc_day[t] > 14)) vmod = 0.1f;
+    if ((w & RH_VACCINATED) && ((int)day - e->buf.cold[t].vacc_day > 14)) vmod = 0.1f;
     int pod = 0;
     int sev = severity_of(e, age, val, vmod, &pod);
     float g = rp_gamma_mu_cv(e->dis.mean_incubation_duration[0], 0.86f, e->k0, e->k1, t, day, RP_P_INFECT, 1);
@@ -224,16 +225,20 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
                   RH_INFECTED_ON((fresh && day == RP_INIT_DAY) ? day + 1u : day);
     e->buf.hot[t] = nw;
     if (src >= 0) {
-        e->buf.infector[t] = src;
-        int old = e->buf.n_infected[src]++;
+        e->buf.cold[t].infector = src;
+        int old = e->buf.cold[src].n_infected++;
         /* the source keeps an infectee list: its START-of-day word, carried in the candidate record
          * (person_expose_others runs before the source's own transition of the day, main.pyx:404-414) */
         if (src_has_list) {
+            /* Person.infectees (main.pyx:128,231): the first REINA_INLINE_INFECTEES by rank in the source's inline block,
+             * the others on its linked list */
             if (old >= 64) {
                 set_problem(e, 1 /* TOO_MANY_INFECTEES */);
+            } else if (old < REINA_INLINE_INFECTEES) {
+                e->buf.infectees[(size_t)src * REINA_INLINE_INFECTEES + (uint32_t)old] = (int32_t)t;
             } else {
-                e->buf.next_sibling[t] = e->buf.first_infectee[src];
-                e->buf.first_infectee[src] = (int32_t)t;
+                e->buf.cold[t].next_sibling = e->buf.cold[src].first_infectee;
+                e->buf.cold[src].first_infectee = (int32_t)t;
             }
         }
     }
@@ -369,27 +374,40 @@ static void run_testing(Par *e, const reina_day_t *dp) {
         /* Q2: level 0 -- infector and infectees of every detected case */
         for (int k = 0; k < n; k++) {
             uint32_t i = q[k];
-            int32_t inf = e->buf.infector[i];
+            int32_t inf = e->buf.cold[i].infector;
             if (inf >= 0 && try_queue(e, (uint32_t)inf, i, dp)) {
                 queue_append(e, nxt, (uint32_t)inf);
                 level1_append(e, (uint32_t)inf);
             }
-            if (e->buf.hot[i] & RH_HASLIST)
-                for (int32_t c = e->buf.first_infectee[i]; c >= 0; c = e->buf.next_sibling[c])
+            if (e->buf.hot[i] & RH_HASLIST) {
+                for (int k = 0; k < REINA_INLINE_INFECTEES; k++) {
+                    const int32_t c = e->buf.infectees[(size_t)i * REINA_INLINE_INFECTEES + k];
+                    if (c >= 0 && try_queue(e, (uint32_t)c, i, dp)) {
+                        queue_append(e, nxt, (uint32_t)c);
+                        level1_append(e, (uint32_t)c);
+                    }
+                }
+                for (int32_t c = e->buf.cold[i].first_infectee; c >= 0; c = e->buf.cold[c].next_sibling)
                     if (try_queue(e, (uint32_t)c, i, dp)) {
                         queue_append(e, nxt, (uint32_t)c);
                         level1_append(e, (uint32_t)c);
                     }
+            }
         }
         /* Q3: level 1 -- their infector and infectees, no further recursion */
         int n1 = CTL(e, REINA_L_LEVEL1);
         for (int k = 0; k < n1; k++) {
             uint32_t i = e->buf.level1[k];
-            int32_t inf = e->buf.infector[i];
+            int32_t inf = e->buf.cold[i].infector;
             if (inf >= 0 && try_queue(e, (uint32_t)inf, i, dp)) queue_append(e, nxt, (uint32_t)inf);
-            if (e->buf.hot[i] & RH_HASLIST)
-                for (int32_t c = e->buf.first_infectee[i]; c >= 0; c = e->buf.next_sibling[c])
+            if (e->buf.hot[i] & RH_HASLIST) {
+                for (int k = 0; k < REINA_INLINE_INFECTEES; k++) {
+                    const int32_t c = e->buf.infectees[(size_t)i * REINA_INLINE_INFECTEES + k];
+                    if (c >= 0 && try_queue(e, (uint32_t)c, i, dp)) queue_append(e, nxt, (uint32_t)c);
+                }
+                for (int32_t c = e->buf.cold[i].first_infectee; c >= 0; c = e->buf.cold[c].next_sibling)
                     if (try_queue(e, (uint32_t)c, i, dp)) queue_append(e, nxt, (uint32_t)c);
+            }
         }
     }
     CTL(e, lcur) = 0;
@@ -410,7 +428,7 @@ static void run_vaccinations(Par *e, const reina_day_t *dp) {
             uint32_t w = e->buf.hot[i];
             if (RH_STATE(w) == RS_DEAD || (w & (RH_VACCINATED | RH_DETECTED))) continue;
             e->buf.hot[i] = w | RH_VACCINATED;
-            e->buf.vacc_day[i] = (int32_t)dp->day;
+            e->buf.cold[i].vacc_day = (int32_t)dp->day;
             CNT(e, REINA_C_VACCINATED, age_of(e, i)) += 1;
             done++;
         }
@@ -437,7 +455,7 @@ static uint32_t onset_word(Par *e, uint32_t i, uint32_t w, uint32_t day) {
     float mu = sev == RV_FATAL ? e->dis.mean_duration_from_onset_to_death[v]
                                : e->dis.mean_duration_from_onset_to_recovery[v];
     float d = rp_gamma_mu_cv(mu, 0.45f, e->k0, e->k1, i, day, RP_P_ONSET, 1);
-    e->buf.onset_days[i] = d;
+    e->buf.cold[i].onset_days = d;
     float f = d;
     if (sev >= RV_SEVERE) f *= e->dis.ratio_of_duration_before_hospitalisation[v];
     w = RH_SET_STATE(w, RS_ILLNESS);
@@ -478,7 +496,7 @@ static void run_scan(Par *e, const reina_day_t *dp) {
         if (st >= RS_RECOVERED) {
             if (!(w & RH_INCLUDED)) {
                 SC(e, REINA_S_TOTAL_INFECTORS) += 1;
-                SC(e, REINA_S_TOTAL_INFECTIONS) += e->buf.n_infected[i];
+                SC(e, REINA_S_TOTAL_INFECTIONS) += e->buf.cold[i].n_infected;
                 e->buf.hot[i] = (w | RH_INCLUDED) & ~RH_ACTIVE;
             }
             continue;
@@ -583,7 +601,7 @@ static void run_hospital_events(Par *e, const reina_day_t *dp) {
         uint32_t i = (uint32_t)((ev >> 2) & 0xFFFFFFFFu);
         uint32_t w = e->buf.hot[i];
         int age = age_of(e, i), v = RH_VARIANT(w), sev = RH_SEV(w);
-        float od = e->buf.onset_days[i];
+        float od = e->buf.cold[i].onset_days;
         if (type == EV_HOSPITALIZE) {
             if (!(w & RH_DETECTED)) {
                 w |= RH_DETECTED;
@@ -675,7 +693,7 @@ int par_set_initial_state(Par *e, const reina_initial_state_t *ic, void *stream)
             }
             w = onset_word(e, t, w, RP_INIT_DAY);
             const int v = RH_VARIANT(w), sev = RH_SEV(w);
-            const float od = e->buf.onset_days[t];
+            const float od = e->buf.cold[t].onset_days;
             if (j < i_ill) {
             } else if (j < i_dead) {
                 w = do_die(e, w, age);
@@ -805,7 +823,7 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
                 float pm = a + b - a * b;
                 if (rp_chance(pm, r.v[3])) continue;
             }
-            if (key < e->buf.claim[t]) e->buf.claim[t] = key;
+            if (key < e->buf.cold[t].claim) e->buf.cold[t].claim = key;
             if ((uint32_t)CTL(e, REINA_L_CAND) >= e->cfg.max_candidates) {
                 set_problem(e, REINA_PROBLEM_CANDIDATE_OVERFLOW);
                 continue;
@@ -886,7 +904,7 @@ static void run_remote(Par *e, const reina_day_t *dp) {
                         }
                 }
                 uint64_t key = rp_order_key(dp->day, prio, src);
-                if (key < e->buf.claim[t]) e->buf.claim[t] = key;
+                if (key < e->buf.cold[t].claim) e->buf.cold[t].claim = key;
                 if ((uint32_t)CTL(e, REINA_L_CAND) >= e->cfg.max_candidates) {
                     set_problem(e, REINA_PROBLEM_CANDIDATE_OVERFLOW);
                     continue;
@@ -905,7 +923,7 @@ static void run_install(Par *e, const reina_day_t *dp) {
     int C = CTL(e, REINA_L_CAND);
     for (int k = 0; k < C; k++) {
         const uint32_t *cd = e->buf.candidates + 4u * (uint32_t)k;
-        if (e->buf.claim[cd[0]] != rp_order_key(dp->day, cd[3], cd[1])) continue;
+        if (e->buf.cold[cd[0]].claim != rp_order_key(dp->day, cd[3], cd[1])) continue;
         if (RH_STATE(e->buf.hot[cd[0]]) != RS_SUSCEPTIBLE) continue; /* duplicate record of the winner */
         int32_t src = (cd[1] & RP_REMOTE_SRC) ? -1 : (int32_t)cd[1];
         install_infection(e, cd[0], dp->day, cd[2] & 0xFFu, src, 0, dp->testing_mode, (cd[2] >> 8) & 1u);

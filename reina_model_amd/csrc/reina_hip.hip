@@ -144,7 +144,7 @@ static void free_engine(reina_engine *e) {
 
 extern "C" {
 
-int reina_abi_version(void) { return 2; }
+int reina_abi_version(void) { return 3; }
 
 #ifdef REINA_ABLATE
 int reina_debug_ablate(uint32_t bits) {   // diagnostic builds only (tools/ablate_day.py)
@@ -543,7 +543,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
         const uint32_t scan_waves = e->cur_scan_waves;
-        int ig = grid_for(N / 64 + 1, HOSP_THREADS, 128) * 2;  // even: candidates / deferred lists
+        int ig = grid_for(N / 64 + 1, HOSP_THREADS, 128) * 2;  // (the work is handed out in units by ticket: any number of workgroups will do)
         // (groups: 128 workgroups for all members together -- every workgroup pays its prologue and its histogram flush)
         if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 2;
         const bool par = e->h_params.hosp_parallel != 0;
@@ -555,14 +555,12 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
             int rest = (int)e->n_cus - (int)n_walk;
             if (K > 1) rest = (int)(e->n_cus / K) - (int)n_walk;
             if (rest > ig) rest = ig;
-            rest &= ~3;
-            if (rest < 4) rest = 4;
+            if (rest < 2) rest = 2;
             LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(n_walk + rest, K), dim3(HOSP_THREADS),
                          (size_t)HOSP_P_THREADS * HOSP_P_E * 8, s, refs, dp, scan_waves, scan_tiles, HI_INSTALL | HI_EVENTS, n_walk);
         } else {
             // workgroup 0 walks the bed / ICU events of a day on which order matters, beside the installs
-            ig &= ~3;   // (four roles)
-            if (ig < 4) ig = K > 1 ? 2 : 4;
+            if (ig < 2) ig = 2;
             LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig + 1, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
                          refs, dp, scan_waves, scan_tiles, HI_HOSP_WG | HI_INSTALL | HI_EVENTS, 0u);
         }

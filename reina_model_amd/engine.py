@@ -45,7 +45,10 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 48
 L_HOSP_PEAK = 12   # control word: bed / ICU event count of the busiest day on which the events' order mattered
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
-ABI_VERSION = 2   # reina_abi_version(): struct layouts of include/reina_hip.h (round 2: no sus_bits, bucketed hosp_events, 48 control words)
+ABI_VERSION = 3   # reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays)
+INLINE_INFECTEES = 8   # REINA_INLINE_INFECTEES
+COLD_WORDS = 8         # sizeof(reina_cold_t) / 4: claim (2 words), infector, n_infected, onset_days, vacc_day, first_infectee, next_sibling
+COLD_FIELDS = dict(infector=2, n_infected=3, onset_days=4, vacc_day=5, first_infectee=6, next_sibling=7)   # word of each 32-bit field
 PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install')
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
@@ -95,8 +98,7 @@ class ContactTablesABI(ctypes.Structure):
                 ('range_min', ctypes.c_int32 * MAX_RANGES), ('range_max', ctypes.c_int32 * MAX_RANGES)]
 
 
-BUFFER_FIELDS = ('hot', 'infector', 'n_infected', 'onset_days', 'vacc_day', 'first_infectee',
-                 'next_sibling', 'claim', 'counters', 'control', 'work_items', 'candidates',
+BUFFER_FIELDS = ('hot', 'cold', 'infectees', 'counters', 'control', 'work_items', 'candidates',
                  'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'mirror_meta', 'work_counts', 'scan_lists')
 
 
@@ -310,10 +312,12 @@ class Engine:
         n = config.n_agents
         a = allocator
         self.tensors = dict(
-            hot=a.zeros(n, np.uint32), infector=a.zeros(n, np.int32), n_infected=a.zeros(n, np.int32),
-            onset_days=a.zeros(n, np.float32), vacc_day=a.zeros(n, np.int32),
-            first_infectee=a.zeros(n, np.int32), next_sibling=a.zeros(n, np.int32),
-            claim=a.zeros(n, np.uint64), counters=a.zeros(COUNTER_WORDS, np.int32),
+            hot=a.zeros(n, np.uint32),
+            # everything touched only at events, one 32-byte record per agent (include/reina_hip.h: reina_cold_t) ...
+            cold=a.zeros(COLD_WORDS * n, np.int32),
+            # ... and the agent's first INLINE_INFECTEES infectees side by side (contact tracing reads them in one access)
+            infectees=a.zeros(INLINE_INFECTEES * n, np.int32),
+            counters=a.zeros(COUNTER_WORDS, np.int32),
             control=a.zeros(L_NR, np.int32),
             work_items=a.zeros(4 * config.max_work_items, np.uint32),
             candidates=a.zeros(4 * config.max_candidates, np.uint32),
@@ -329,6 +333,10 @@ class Engine:
         )
         bufs = Buffers(**{k: a.ptr(v) for k, v in self.tensors.items()})
         self._check(self.f['bind_buffers'](self._h, ctypes.byref(bufs)), 'bind_buffers')
+        # the 32-bit fields of the cold record by name: strided views of `cold` (what the parity tests compare)
+        rec = self.tensors['cold'].reshape(n, COLD_WORDS)
+        for name, word in COLD_FIELDS.items():
+            self.tensors[name] = rec[:, word]
         self._keep = []
 
     def _check(self, rc, what):

@@ -40,16 +40,20 @@ def _assert_state_equal(gpu, cpu):
         qa = np.sort(gpu.engine.alloc.to_host(tg[q])[:cg[l]].view(np.uint32))
         qb = np.sort(np.asarray(tc[q])[:cc[l]].view(np.uint32))
         assert np.array_equal(qa, qb), q
-    # infectee lists: same sets per infector (insertion order is free) -- EVERY chain, walked in lock-step
+    # infectee lists: same sets per infector (insertion order is free) -- EVERY inline slot and EVERY overflow chain
     fa = gpu.engine.alloc.to_host(tg['first_infectee'])
     na = gpu.engine.alloc.to_host(tg['next_sibling'])
     fb, nb = np.asarray(tc['first_infectee']), np.asarray(tc['next_sibling'])
+    ia = gpu.engine.alloc.to_host(tg['infectees']).reshape(-1, eng.INLINE_INFECTEES)
+    ib = np.asarray(tc['infectees']).reshape(-1, eng.INLINE_INFECTEES)
 
-    def chain_pairs(f, n):
-        """sorted (infector, infectee) pairs of all lists; a list holds at most 64 entries (main.pyx:128)"""
+    def chain_pairs(inline, f, n):
+        """sorted (infector, infectee) pairs of all lists: the inline slots (-1 = empty) and the linked overflow list; a list
+        holds at most 64 entries (main.pyx:128)"""
+        o, k = np.nonzero(inline >= 0)
+        pairs = [o.astype(np.int64) * (1 << 32) + inline[o, k].astype(np.int64)]
         owner = np.nonzero(f >= 0)[0].astype(np.int64)
         cur = f[owner].astype(np.int64)
-        pairs = []
         for _ in range(70):
             if len(cur) == 0:
                 break
@@ -58,9 +62,14 @@ def _assert_state_equal(gpu, cpu):
             keep = nxt >= 0
             owner, cur = owner[keep], nxt[keep]
         assert len(cur) == 0, 'an infectee list longer than 64 entries (or a cycle)'
-        return np.sort(np.concatenate(pairs)) if pairs else np.zeros(0, dtype=np.int64)
+        return np.sort(np.concatenate(pairs))
 
-    assert np.array_equal(chain_pairs(fa, na), chain_pairs(fb, nb)), 'infectee lists'
+    pa, pb = chain_pairs(ia, fa, na), chain_pairs(ib, fb, nb)
+    assert np.array_equal(pa, pb), 'infectee lists'
+    # an inline block is filled by rank: no hole before a used slot, and the overflow list starts only when it is full
+    used = (ia >= 0).sum(axis=1)
+    assert np.array_equal(ia >= 0, np.arange(eng.INLINE_INFECTEES)[None, :] < used[:, None]), 'inline infectee slots are filled in rank order'
+    assert np.all(used[fa >= 0] == eng.INLINE_INFECTEES), 'an overflow list beside a block that is not full'
 
 
 def _run_and_compare(variables, ages, seed, days, interventions=None, chunk=None, ipc=None):
