@@ -101,7 +101,9 @@ enum {
     REINA_L_WALK_TICKET,                                /* a large population's ordered event walk: the next priority bucket to be handed out
                                                            (zeroed by the day's opening) */
     REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
-    REINA_L_NR = 48
+    REINA_L_DET_SIDE = 48,                              /* [REINA_MAX_AGES] the day's detections by age from the test queue (the day's opening
+                                                           launch), folded into the counters by the day's last launch */
+    REINA_L_NR = 48 + REINA_MAX_AGES
 };
 
 /* The day's bed / ICU events are kept in buckets by priority range (buffers.hosp_events, 64-bit words):

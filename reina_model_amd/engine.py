@@ -42,7 +42,7 @@ S_DAILY_CONTACTS = 16
 S_INFECTED_BY_VARIANT = 24
 S_NR = 32
 COUNTER_WORDS = C_NR * MAX_AGES + S_NR
-L_NR = 48
+L_NR = 48 + MAX_AGES   # REINA_L_NR (48 named words and cursors + the detections-by-age side block)
 L_HOSP_PEAK = 12   # control word: bed / ICU event count of the busiest day on which the events' order mattered
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
 ABI_VERSION = 3   # reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays)

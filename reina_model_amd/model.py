@@ -607,7 +607,7 @@ class Context:
     def _run_streamed(self, days, record_history):
         """run() for an unsharded population, or a sharded one whose engine queues the per-day
         all-reduce itself (reina_set_collective): day descriptors are built on the host and handed to
-        the library in growing chunks, so the GPU works on the first days while the host is still
+        the library in growing chunks (1, 2, 4, ... 64 days), so the GPU works on the first days while the host is still
         turning the intervention schedule into the later ones (table uploads are queued copies from
         pinned staging, they do not drain the stream either)."""
         a = self.engine.alloc
@@ -618,7 +618,7 @@ class Context:
         base = a.ptr(hist) if record_history else None
         row = 4 * _eng.COUNTER_WORDS
         self.mobility_history = []
-        pending, issued, chunk = [], 0, 4
+        pending, issued, chunk = [], 0, 1   # (1, 2, 4, ... 64 days per call: day 0 runs on the GPU while day 1 is being planned)
 
         def flush():
             nonlocal pending, issued, chunk
