@@ -498,8 +498,12 @@ def main():
             'roofline': roofline_obj(n_agents, res, a.steps, stride, traffic_key),
         }
         if world > 1:
-            out['rccl_world'] = res['rccl_world']   # ncclCommCount of the communicator the day stream's all-reduce runs on
+            # how the per-day exchange ran: ncclCommCount of the communicator the day stream's in-stream all-reduce uses, or null
+            # when the direct communicator could not be built and the exchange fell back to torch.distributed.all_reduce
+            out['rccl_world'] = res['rccl_world']
             out['config']['rccl_world'] = res['rccl_world']
+            out['config']['collective'] = ('ncclAllReduce queued on the day stream (own RCCL communicator)' if res['rccl_world']
+                                           else 'torch.distributed.all_reduce (%s backend; direct RCCL communicator unavailable)' % dist.get_backend())
 
         def extra(store, key, fn):
             # the additional workloads must not take the headline line down with them
@@ -509,6 +513,8 @@ def main():
                 store[key] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
         def full_line(n_cfg, label):
+            import gc
+            gc.collect()   # (the previous size's Contexts sit in reference cycles: several GB of HBM each at 1e8-2e8 agents)
             if n_cfg:
                 vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), n_cfg)
                 key = str(n_cfg)

@@ -543,7 +543,15 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
         const uint32_t scan_waves = e->cur_scan_waves;
-        int ig = grid_for(N / 64 + 1, HOSP_THREADS, 128) * 2;  // (the work is handed out in units by ticket: any number of workgroups will do)
+        // installing workgroups: one wave per unit of a quiet day (3 lists of scan_waves / 8 units + the event buckets), so
+        // that no wave walks two dependent chains one after the other; at most one workgroup per CU
+        int ig = grid_for(N / 64 + 1, HOSP_THREADS, 128) * 2;
+        {
+            const uint32_t units = 3u * ((scan_waves + 7u) / 8u) + (e->h_params.hosp_ranges + 7u) / 8u;
+            const int want = (int)((units + HOSP_THREADS / 64 - 1) / (HOSP_THREADS / 64));
+            if (want > ig) ig = want;
+            if (ig > (int)e->n_cus) ig = (int)e->n_cus;
+        }
         // (groups: 128 workgroups for all members together -- every workgroup pays its prologue and its histogram flush)
         if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 2;
         const bool par = e->h_params.hosp_parallel != 0;

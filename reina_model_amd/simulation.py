@@ -129,7 +129,7 @@ def simulate_individuals(variables=None, step_callback=None, callback_day_interv
         df = pd.DataFrame(rows, index=date_index[:done], columns=cols).reindex(date_index)
         if not step_callback(df):
             raise ExecutionInterrupted()
-    df = pd.DataFrame(rows, index=date_index, columns=cols)
+    df = pd.DataFrame(rows, index=date_index, columns=cols).astype(np.float64).astype(object)
     adf = pd.DataFrame(
         ag_array.flatten(),
         index=pd.MultiIndex.from_product([date_index, POP_ATTRS, age_groups], names=['date', 'attr', 'age_group']),
@@ -162,10 +162,9 @@ def _frames_from_history(ctx, hist, mobility_history, start_date, ms_per_day=0.0
         data[attr] = ag_array[:, idx, :].sum(axis=1)
     sc = hist[:, _eng.C_NR * A:].astype(np.int64)
     infections, infectors = sc[:, _eng.S_TOTAL_INFECTIONS], sc[:, _eng.S_TOTAL_INFECTORS]
-    r = np.zeros(days, dtype=object)   # the reference's `r` is the int 0 until more than 5 infectors were seen
+    r = np.zeros(days, dtype=np.float64)   # 0 until more than 5 infectors were seen (main.pyx:1827)
     ok = infectors > 5
     r[ok] = infections[ok] / infectors[ok]
-    r[~ok] = 0
     data['exposed_per_day'] = sc[:, _eng.S_EXPOSED_PER_DAY]
     data['available_hospital_beds'] = sc[:, _eng.S_AVAILABLE_BEDS]
     data['available_icu_units'] = sc[:, _eng.S_AVAILABLE_ICU]
@@ -177,7 +176,9 @@ def _frames_from_history(ctx, hist, mobility_history, start_date, ms_per_day=0.0
         data['exposures_%s' % place] = sc[:, _eng.S_DAILY_CONTACTS + i]
     infected = data['infected'].astype(np.float64)
     data['us_per_infected'] = np.where(infected > 0, ms_per_day * 1000 / np.where(infected > 0, infected, 1), 0)
-    df = pd.DataFrame(data, index=date_index, columns=cols)
+    # (the reference assembles its frame from per-day dicts and reindexes it on every progress report: what reaches the caller
+    # holds Python floats in object columns -- recorded from the real driver in tests/golden/frames_ref.json; same here)
+    df = pd.DataFrame({c: np.asarray(data[c], dtype=np.float64) for c in cols}, index=date_index, columns=cols).astype(object)
     if not want_adf:
         return df, None
     adf = pd.DataFrame(
@@ -272,6 +273,27 @@ def run_monte_carlo(scenario_name, seeds=range(1000), device='cuda:0', group_siz
     return df
 
 
+def table_header():
+    """header line of the day table the reference prints when run as a script (calc/simulation.py:411-421)"""
+    header = '%-10s' % 'day'
+    for attr in POP_ATTRS + ['ct_cases_per_day', 'r'] + ['exposures', 'us_per_infected']:
+        header += '%15s' % attr
+    return header
+
+
+def table_row(rec):
+    """one line of that table from a row of df (calc/simulation.py:423-441)"""
+    s = '%-12s' % rec.name.date().isoformat()
+    for attr in POP_ATTRS:
+        s += '%15d' % rec[attr]
+    s += '%15d' % rec['ct_cases_per_day']
+    s += '%13.2f' % rec['r']
+    s += '%15d' % sum(rec[x] for x in rec.index if 'exposures_' in x)
+    if rec['infected']:
+        s += '%13.2f' % rec['us_per_infected']
+    return s
+
+
 def main(argv=None):
     """The day table the reference prints when run as a script (calc/simulation.py:411-447)."""
     import argparse
@@ -288,23 +310,11 @@ def main(argv=None):
         v['simulation_days'] = a.days
     if a.seed is not None:
         v['random_seed'] = a.seed
-    state_attrs = ['ct_cases_per_day', 'r']
-    header = '%-10s' % 'day'
-    for attr in POP_ATTRS + state_attrs + ['exposures', 'us_per_infected']:
-        header += '%15s' % attr
-    print(header)
+    print(table_header())
 
     def step_callback(df):
         for _, rec in df.dropna().iloc[-a.interval:].iterrows():
-            s = '%-12s' % rec.name.date().isoformat()
-            for attr in POP_ATTRS:
-                s += '%15d' % rec[attr]
-            s += '%15d' % rec['ct_cases_per_day']
-            s += '%13.2f' % rec['r']
-            s += '%15d' % sum(rec[x] for x in rec.index if 'exposures_' in x)
-            if rec['infected']:
-                s += '%13.2f' % rec['us_per_infected']
-            print(s)
+            print(table_row(rec))
         return True
 
     df, adf = simulate_individuals(v, step_callback=step_callback, callback_day_interval=a.interval, device=a.device)

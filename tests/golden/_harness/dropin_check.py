@@ -36,7 +36,8 @@ with variables.allow_set_variable():
 
 assert list(ref_df.columns) == list(our_df.columns), (list(ref_df.columns), list(our_df.columns))
 assert list(ref_adf.columns) == list(our_adf.columns) and ref_df.index.equals(our_df.index)
-assert (ref_df.dtypes.astype(str).values == our_df.dtypes.astype(str).values).all() or True
+assert (ref_df.dtypes.astype(str).values == our_df.dtypes.astype(str).values).all()
+assert (ref_adf.dtypes.astype(str).values == our_adf.dtypes.astype(str).values).all() and ref_adf.index.equals(our_adf.index)
 tot = int(our_df[['susceptible', 'infected', 'recovered', 'dead']].iloc[-1].sum())
 assert tot == 1685983, tot
 # same model, different random streams: the two runs agree loosely already on one seed

@@ -110,3 +110,68 @@ def test_kernels_fit_the_lds_they_ask_for():
         # the streaming kernel must not touch scratch; the day's last launch (event walk + installs in one kernel) may
         # park a handful of registers
         assert v.get('.vgpr_spill_count:', 0) <= (8 if 'k_hosp_install' in k else 0), (k, v)
+
+
+def test_k_day_keeps_its_hand_reserved_registers_to_itself():
+    """k_day holds three in-flight tiles in v104..v127 by hand (inline asm; the kernel is compiled for 104 VGPRs and the
+    descriptor allocates 128).  That is sound only while (a) nothing is CALLED from the kernel -- a callee could use any
+    register --, (b) nothing is spilled to scratch, and (c) no instruction the compiler emitted touches v104 and above: the
+    only writers are the asm block's global_load_dwordx4, the only readers its v_bfe_u32 (round-2 advisor finding)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from reina_model_amd import build
+    tools = '/opt/rocm/lib/llvm/bin'
+    assert os.path.exists(os.path.join(tools, 'llvm-objdump')), 'llvm-objdump is part of the ROCm image: this test does not skip'
+    build.build()
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, 'lib.so')
+        shutil.copy(build.LIB, so)
+        subprocess.run([os.path.join(tools, 'llvm-objdump'), '--offloading', so], check=True, capture_output=True, cwd=tmp)
+        co = [f for f in os.listdir(tmp) if 'gfx950' in f][0]
+        dis = subprocess.run([os.path.join(tools, 'llvm-objdump'), '-d', os.path.join(tmp, co)], check=True, capture_output=True, text=True).stdout
+        notes = subprocess.run([os.path.join(tools, 'llvm-readelf'), '--notes', os.path.join(tmp, co)], check=True, capture_output=True, text=True).stdout
+    inside, body = False, []
+    for line in dis.splitlines():
+        m = re.match(r'^[0-9a-f]+ <(.*)>:$', line)
+        if m:
+            inside = 'k_day' in m.group(1) and not m.group(1).endswith('.kd')
+            continue
+        if inside and line.strip():
+            body.append(line.split('//')[0].strip())
+    assert len(body) > 1000
+    high = re.compile(r'\bv(?:\[)?(1(?:0[4-9]|1[0-9]|2[0-7]))\b')   # v104..v127, alone or as the start of a range
+    loads = reads = 0
+    for ins in body:
+        op = ins.split()[0]
+        assert not op.startswith(('s_swappc', 's_call', 's_setpc')), 'k_day calls out: %s' % ins
+        assert not op.startswith('scratch_'), 'k_day touches scratch: %s' % ins
+        regs = [int(x) for x in re.findall(r'\bv\[?(\d+)', ins)]
+        if not any(r >= 104 for r in regs):
+            # (a range that starts below 104 must not reach into the reserved set either)
+            for a, b in re.findall(r'v\[(\d+):(\d+)\]', ins):
+                assert int(b) < 104, ins
+            continue
+        if op == 'global_load_dwordx4':
+            dst = re.match(r'global_load_dwordx4\s+v\[(\d+):(\d+)\]', ins)
+            assert dst and 104 <= int(dst.group(1)) and int(dst.group(2)) <= 127, ins
+            loads += 1
+        else:
+            assert op == 'v_bfe_u32', 'a compiler-scheduled instruction touches the reserved tile registers: %s' % ins
+            ops = [x.strip(' ,') for x in ins.split()[1:]]
+            assert not re.match(r'v\[?1(0[4-9]|1\d|2[0-7])', ops[0]), 'v_bfe_u32 writes a reserved register: %s' % ins
+            reads += 1
+    assert loads >= 6 and reads >= 24, (loads, reads)
+    # kernel descriptor: no scratch at all
+    name, fields = None, {}
+    for line in notes.splitlines():
+        line = line.strip()
+        if line.startswith('.private_segment_fixed_size:') or line.startswith('.vgpr_spill_count:') or line.startswith('.sgpr_spill_count:'):
+            fields[line.split(':')[0]] = int(line.split()[-1])
+        if line.startswith('.name:'):
+            name = line.split()[-1]
+        if line.startswith('.wavefront_size:'):
+            if name and 'k_day' in name:
+                assert fields.get('.private_segment_fixed_size', 0) == 0 and fields.get('.vgpr_spill_count', 0) == 0, fields
+            name, fields = None, {}

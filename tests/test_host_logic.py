@@ -297,3 +297,85 @@ def test_initial_condition_walk_is_cut_short_like_the_reference_walks_it():
     ipc2 = datasets.InitialPopulationCondition(dead=5, in_icu=4, in_ward=12, incubating=60, ill=45, recovered=300)
     ctx._set_initial_state(ipc2)
     assert seen['ic'].were_incubating == ipc2.were_incubating() == 426
+
+
+def _reference_frames():
+    import os
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'frames_ref.json')) as f:
+        return json.load(f)
+
+
+def test_frames_equal_the_reference_drivers_own_frames():
+    """SURVEY 8 row f-3, pinned to the REAL reference: tests/golden/frames_ref.json holds the (df, adf) frames that
+    calc.simulation.simulate_individuals itself returned for a 40-day HUS run of the real cythonsim (recorded by
+    tests/golden/_harness/make_frames_fixture.py: column order, dtypes, index, the adf MultiIndex layout, every value).
+    The same per-day numbers, put back into a counter history, must come out of reina_model_amd.simulation as the same
+    frames: labels, order, dtypes, index, element types and values."""
+    pd = pytest.importorskip('pandas')
+    from datetime import date
+    from fractions import Fraction
+    from reina_model_amd import engine as eng
+    f = _reference_frames()
+    days, A = f['days'], eng.MAX_AGES
+    ref_cols = f['df']['columns']
+    assert ref_cols == simulation.POP_ATTRS + simulation.STATE_ATTRS + simulation.EXPOSURES_ATTRS + ['us_per_infected']
+    age_to_group = datasets.make_age_groups(VARIABLE_DEFAULTS['max_age'])
+    groups = list(np.unique(age_to_group))
+    adf_cols = [tuple(c) for c in f['adf']['columns']]
+    assert [g for a, g in adf_cols if a == adf_cols[0][0]] == groups          # the age-group labels and their order
+    indices = np.array([groups.index(x) for x in age_to_group])
+    first_age = [int(np.nonzero(indices == g)[0][0]) for g in range(len(groups))]
+    # the reference's numbers as a counter history: a group's value sits at the group's first age
+    hist = np.zeros((days, eng.COUNTER_WORDS), dtype=np.int32)
+    adf_vals = np.asarray(f['adf']['values'], dtype=np.int64)
+    for k, (attr, g) in enumerate(adf_cols):
+        hist[:, eng.C_NAMES.index(attr) * A + first_age[groups.index(g)]] = adf_vals[:, k]
+    sc = hist[:, eng.C_NR * A:]
+    v = f['df']['values']
+    for name, slot in (('exposed_per_day', eng.S_EXPOSED_PER_DAY), ('available_hospital_beds', eng.S_AVAILABLE_BEDS),
+                       ('available_icu_units', eng.S_AVAILABLE_ICU), ('total_icu_units', eng.S_ICU_UNITS),
+                       ('ct_cases_per_day', eng.S_CT_CASES_PER_DAY)):
+        sc[:, slot] = np.asarray(v[name], dtype=np.int64)
+    for i, place in enumerate(('home', 'work', 'school', 'transport', 'leisure', 'other')):
+        sc[:, eng.S_DAILY_CONTACTS + i] = np.asarray(v['exposures_' + place], dtype=np.int64)
+    for d, r in enumerate(v['r']):   # r = total_infections / total_infectors (more than 5 infectors), else 0
+        fr = Fraction(r).limit_denominator(100000)
+        k = 1 if fr.denominator > 5 else 6
+        assert r == 0 or fr.numerator * k / (fr.denominator * k) == r
+        sc[d, eng.S_TOTAL_INFECTIONS], sc[d, eng.S_TOTAL_INFECTORS] = (fr.numerator * k, fr.denominator * k) if r else (0, 0)
+    mobility = [float(np.float32(1.0 - x)) for x in v['mobility_limitation']]   # (the reference keeps the factor as a C float)
+    assert [1 - m for m in mobility] == v['mobility_limitation']
+
+    class Ctx:
+        nr_ages = len(age_to_group)
+        age_group_labels = groups
+        age_group_indices = indices
+
+    df, adf = simulation._frames_from_history(Ctx, hist, mobility, date.fromisoformat(f['start']), ms_per_day=1.0)
+    # df: labels, order, dtypes, index
+    assert list(df.columns) == ref_cols
+    assert [str(t) for t in df.dtypes] == f['df']['dtypes']
+    assert type(df.index).__name__ == f['df']['index_type'] and str(df.index.dtype) == f['df']['index_dtype']
+    assert df.index.name == f['df']['index_name'] and str(df.index.freqstr) == f['df']['index_freq']
+    assert str(df.index[0].date()) == f['start'] and len(df) == days
+    for c in ref_cols:
+        assert sorted(set(type(x).__name__ for x in df[c].values)) == f['df']['element_types'][c], c
+        if c != 'us_per_infected':   # (a timing column)
+            assert df[c].tolist() == v[c], c
+    # adf: the two-level column index (attr, age_group) in the reference's order, names, dtype, index, values
+    assert adf.columns.nlevels == f['adf']['nlevels'] and list(adf.columns.names) == f['adf']['column_names']
+    assert [tuple(c) for c in adf.columns] == adf_cols
+    assert sorted(set(str(t) for t in adf.dtypes)) == f['adf']['dtypes']
+    assert type(adf.index).__name__ == f['adf']['index_type'] and adf.index.name == f['adf']['index_name']
+    assert str(adf.index.dtype) == f['adf']['index_dtype']
+    assert np.array_equal(adf.values, adf_vals)
+    # ... and the day table `python -m calc.simulation` prints: header line and rows, character for character
+    assert simulation.table_header() == f['printed']['header']
+    for d, line in enumerate(f['printed']['rows']):
+        ours = simulation.table_row(df.iloc[d])
+        if df['infected'].iloc[d]:   # the line ends with the timing column: same text up to it, then a number in its own width
+            cut = len(ours) - 13
+            assert ours[:cut] == line[:cut] and float(line[cut:]) >= 0, (d, ours, line)
+        else:
+            assert ours == line, (d, ours, line)

@@ -669,6 +669,49 @@ def test_config3_at_full_size_eight_shards_of_fifty_million():
     assert tot('all_infected') > 20_000_000
 
 
+def test_config2_fifty_million_agents_against_oracle_b():
+    """BASELINE configs[2] at its stated size (5 x 10^7 synthetic agents, one GPU): the first 130 days of the scaled default
+    scenario -- through the peak of the first wave, with beds and ICU units saturated and the ordered event walk of a large
+    population on every one of those days -- per-day counter blocks and the final per-agent state bit for bit against
+    oracle B (about half a minute of CPU).  Round 2 had this as a hand-run one-off (tools/parity_50m.py)."""
+    import bench
+    v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 50_000_000)
+    gpu, cpu = _run_and_compare(v, ages, 0, 130, chunk=65)
+    c = gpu.per_age_counters()
+    assert c['all_infected'].sum() > 5_000_000
+    peak = int(gpu.engine.alloc.to_host(gpu.engine.tensors['control'])[eng.L_HOSP_PEAK])
+    assert peak > 10_000, peak   # the ordered walk really ran on a day with tens of thousands of events
+
+
+def test_sharded_hundred_million_through_the_saturated_peak_against_oracle_b():
+    """BASELINE configs[3] shape on one GPU: 4 shards x 25 M agents stepped in lock-step for 110 days -- the cross-shard
+    pressure, the mirror tables, the demand-proportional split of the pooled beds / ICU units while they are SATURATED
+    (days 85-110) and every shard's ordered event walk -- per-shard counter blocks every tenth day and the final per-agent
+    state bit for bit against oracle B sharded the same way.  (Round 2's suite compared the sharded engine with the oracle
+    for the first 40 days only, before the wave.)"""
+    import bench
+    import par_backend
+    from reina_model_amd import sharding
+    G, days = 4, 110
+    v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 100_000_000)
+    gm, cm = [], []
+    gpu = [simulation.make_context(v, age_counts=ages, seed=6, comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
+    cpu = [simulation.make_context(v, age_counts=ages, seed=6, comm=sharding.InProcessComm(r, G, cm),
+                                   engine_factory=par_backend.par_engine_factory) for r in range(G)]
+    for d in range(days):
+        sharding.step_shards_together(gpu)
+        sharding.step_shards_together(cpu)
+        if d % 10 == 9 or d == days - 1:
+            for a, b in zip(gpu, cpu):
+                assert np.array_equal(a.engine.read_counters(), b.engine.read_counters()), 'day %d' % d
+    for a, b in zip(gpu, cpu):
+        _assert_state_equal(a, b)
+        # every shard has been through days on which its share of the beds / ICU units could run out (ordered walks of
+        # thousands of events): the saturated regime was reached
+        peak = int(a.engine.alloc.to_host(a.engine.tensors['control'])[eng.L_HOSP_PEAK])
+        assert peak > 2000, peak
+
+
 def test_config5_per_gpu_batch_of_128_hus_members():
     """BASELINE config 5's per-GPU batch: 128 seeds x HUS 1 685 983 agents as ONE engine group (one launch
     per phase for all 128; the day-opening launch is 128 x 66 workgroups whose roles are handed out by
@@ -708,6 +751,19 @@ def test_driver_contract_on_the_hip_engine():
     pd.testing.assert_frame_equal(df_g[cols], df_c[cols])
     pd.testing.assert_frame_equal(adf_g, adf_c)
     assert df_g['all_infected'].iloc[-1] > 500 and adf_g.shape == (90, 12 * 9)
+    # ... and the frames have the layout of the frames the REFERENCE's own driver returned with the real cythonsim behind it
+    # (tests/golden/frames_ref.json, recorded by tests/golden/_harness/make_frames_fixture.py; the values of that recording
+    # are compared in tests/test_host_logic.py)
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'frames_ref.json')) as fh:
+        ref = json.load(fh)
+    for df_x, adf_x in ((df_g, adf_g),):
+        assert list(df_x.columns) == ref['df']['columns'] and [str(t) for t in df_x.dtypes] == ref['df']['dtypes']
+        assert type(df_x.index).__name__ == ref['df']['index_type'] and df_x.index.name == ref['df']['index_name']
+        assert str(df_x.index.freqstr) == ref['df']['index_freq'] and str(df_x.index.dtype) == ref['df']['index_dtype']
+        assert [list(c) for c in adf_x.columns] == ref['adf']['columns'] and list(adf_x.columns.names) == ref['adf']['column_names']
+        assert sorted(set(str(t) for t in adf_x.dtypes)) == ref['adf']['dtypes'] and adf_x.index.name == ref['adf']['index_name']
     # the callback path: frames grow by `callback_day_interval` rows, same numbers; returning False interrupts
     seen = []
 
@@ -717,9 +773,7 @@ def test_driver_contract_on_the_hip_engine():
 
     df_s, adf_s = simulation.simulate_individuals(v, age_counts=ages, step_callback=cb, callback_day_interval=7)
     assert seen == list(range(7, 90, 7)) + [90]
-    # (`r` is the int 0 until more than 5 infectors were seen, main.pyx:1817: an object column in the frame
-    # assembled from the whole history, a float column once NaN-padded callback frames were involved)
-    pd.testing.assert_frame_equal(df_s[cols].astype({'r': float}), df_c[cols].astype({'r': float}))
+    pd.testing.assert_frame_equal(df_s[cols], df_c[cols])
     pd.testing.assert_frame_equal(adf_s, adf_c)
     calls = []
     with pytest.raises(simulation.ExecutionInterrupted):
