@@ -105,6 +105,14 @@ static bool kind_timed(int today, int kind) {
         }                                                                                                                \
     } while (0)
 
+// a kernel of the day: the GROUP instantiation for an engine group (members found in `refs`), else the single engine's
+// MemberRef by value (k_common.inc: DAY_KERNEL)
+#define LAUNCH_DAY(e, today, kind, kernel, grid, block, lds, stream, ...)                                                \
+    do {                                                                                                                 \
+        if (K > 1) LAUNCH_TIMED(e, today, kind, (kernel<true>), grid, block, lds, stream, refs, (e)->h_ref, __VA_ARGS__); \
+        else LAUNCH_TIMED(e, today, kind, (kernel<false>), grid, block, lds, stream, refs, (e)->h_ref, __VA_ARGS__);      \
+    } while (0)
+
 static void resolve_profile(reina_engine *e) {
     for (int k = 0; k < REINA_PK_NR; k++) {
         for (auto &p : e->kpairs[k]) {
@@ -284,9 +292,13 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK_OR(hipMalloc(&e->d_ref, sizeof(MemberRef)), free_engine(e));
     HIP_CHECK_OR(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice), free_engine(e));
     HIP_CHECK_OR(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice), free_engine(e));
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)((size_t)REINA_MAX_HOSP_EVENTS * 8)), free_engine(e));
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)((size_t)REINA_MAX_HOSP_EVENTS * 8)), free_engine(e));
     *out = e;
     return REINA_OK;
@@ -315,6 +327,7 @@ int reina_bind_buffers(reina_engine_t *e, const reina_buffers_t *b) {
     r.history_base = nullptr;
 
     HIP_CHECK(hipMemcpy(e->d_ref, &r, sizeof(MemberRef), hipMemcpyHostToDevice));
+    e->h_ref = r;
     return REINA_OK;
 }
 
@@ -513,20 +526,19 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     {
         const int g = 2 + tg;
         if (!e->testing_ever) {
-            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open, dim3(2, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own, 0);
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(2, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0);
         } else if (ct && N <= 8000000u) {
-            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own, 3);  // detects + traces, both levels
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 3);  // detects + traces, both levels
         } else if (ct) {
-            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own, 2);  // detects + traces level 0
-            LAUNCH_TIMED(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 2);  // detects + traces level 0
+            LAUNCH_DAY(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, dp);
         } else {
-            LAUNCH_TIMED(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, refs, dp, hist_slot, weekly_own, 1);
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 1);
         }
         // a vaccination programme: its pass over the agents comes after the test queue and before the stream
         // (HealthcareSystem.iterate, main.pyx:514-558)
-        if (dp.n_vaccinations) LAUNCH_TIMED(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, refs, dp);
-        LAUNCH_TIMED(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s,
-                     refs, dp, lds_rows, lds_crows);
+        if (dp.n_vaccinations) LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, dp);
+        LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows);
     }
     e->cur_scan_waves = day_blocks * DAY_WAVES;   // (the day's later launches walk the per-wave slices)
     (void)scan_tiles;
@@ -539,7 +551,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
     const int today = profiled_kind(e, dp.day);
     const bool sharded = e->cfg.n_shards > 1;
     if (sharded)   // (also takes this shard's share of the pooled free beds / ICU units: the walk below starts from it)
-        LAUNCH_TIMED(e, today, REINA_PK_REMOTE, k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, refs, dp);
+        LAUNCH_DAY(e, today, REINA_PK_REMOTE, k_remote, dim3(grid_for(N / 256 + 1, 256, 256), K), dim3(256), 0, s, dp);
     {
         const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
         const uint32_t scan_waves = e->cur_scan_waves;
@@ -564,13 +576,12 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
             if (K > 1) rest = (int)(e->n_cus / K) - (int)n_walk;
             if (rest > ig) rest = ig;
             if (rest < 2) rest = 2;
-            LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(n_walk + rest, K), dim3(HOSP_THREADS),
-                         (size_t)HOSP_P_THREADS * HOSP_P_E * 8, s, refs, dp, scan_waves, scan_tiles, HI_INSTALL | HI_EVENTS, n_walk);
+            LAUNCH_DAY(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(n_walk + rest, K), dim3(HOSP_THREADS),
+                         (size_t)HOSP_P_THREADS * HOSP_P_E * 8, s, dp, scan_waves, scan_tiles, HI_INSTALL | HI_EVENTS, n_walk);
         } else {
             // workgroup 0 walks the bed / ICU events of a day on which order matters, beside the installs
             if (ig < 2) ig = 2;
-            LAUNCH_TIMED(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig + 1, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s,
-                         refs, dp, scan_waves, scan_tiles, HI_HOSP_WG | HI_INSTALL | HI_EVENTS, 0u);
+            LAUNCH_DAY(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig + 1, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s, dp, scan_waves, scan_tiles, HI_HOSP_WG | HI_INSTALL | HI_EVENTS, 0u);
         }
     }
     HIP_CHECK(hipGetLastError());
@@ -731,14 +742,20 @@ int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_d
     for (auto m : g->members) tested = tested || m->testing_ever;
     for (uint32_t d = 0; d < n_days; d++) tested = tested || days[d].testing_mode != RT_NO_TESTING;
     e0->testing_ever = e0->testing_ever || (tested && n_days == 0);
+    // (a group of ONE member launches the single-engine kernels, which take the member by value: its history base for this run)
+    const MemberRef own_ref = e0->h_ref;
+    if (K == 1) e0->h_ref.history_base = g->h_refs[0].history_base;
     for (uint32_t d = 0; d < n_days; d++) {
         reina_day_t dp = days[d];
         dp.history_row = nullptr;
         int rc = launch_day_begin(e0, g->d_refs, K, dp, d, s);
-        if (rc) return rc;
-        rc = launch_day_end(e0, g->d_refs, K, dp, s);
-        if (rc) return rc;
+        if (rc == REINA_OK) rc = launch_day_end(e0, g->d_refs, K, dp, s);
+        if (rc) {
+            e0->h_ref = own_ref;
+            return rc;
+        }
     }
+    e0->h_ref = own_ref;
     for (auto m : g->members) {
         m->testing_ever = m->testing_ever || e0->testing_ever;
         m->cur_scan_waves = e0->cur_scan_waves;

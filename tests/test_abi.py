@@ -96,16 +96,17 @@ def test_kernels_fit_the_lds_they_ask_for():
             fields, name = {}, None
     day = [v for k, v in kernels.items() if 'k_day' in k]
     hosp = [v for k, v in kernels.items() if 'k_hosp_install' in k]
-    assert len(day) == 1 and len(hosp) == 1, sorted(kernels)
+    assert len(day) == 2 and len(hosp) == 2, sorted(kernels)   # (two instantiations each: single engine / engine group)
     LDS = 160 * 1024
     # dynamic requests: reina_hip.hip (day_shared_bytes(REINA_LDS_ROWS, sharded), REINA_MAX_HOSP_EVENTS * 8)
-    assert hosp[0]['.group_segment_fixed_size:'] + eng.MAX_HOSP_EVENTS * 8 <= LDS
+    for h in hosp:
+        assert h['.group_segment_fixed_size:'] + eng.MAX_HOSP_EVENTS * 8 <= LDS
     text = open(os.path.join(ROOT, 'reina_model_amd', 'csrc', 'k_contacts.inc')).read()
     assert 'struct DayShared' in text
-    assert day[0]['.group_segment_fixed_size:'] <= 3072     # (its big arrays are carved from the dynamic part: the
+    assert all(d['.group_segment_fixed_size:'] <= 3072 for d in day)     # (its big arrays are carved from the dynamic part: the
     #                                                          static_assert in k_contacts.inc leaves 3 KB for the rest)
     # k_day addresses v104..v127 by hand (three tiles in flight, inline asm): the kernel descriptor must allocate them
-    assert day[0]['.vgpr_count:'] == 128, day[0]
+    assert all(d['.vgpr_count:'] == 128 for d in day), day
     for k, v in kernels.items():
         # the streaming kernel must not touch scratch; the day's last launch (event walk + installs in one kernel) may
         # park a handful of registers
