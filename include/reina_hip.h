@@ -37,11 +37,21 @@ extern "C" {
 #define REINA_MAX_DAYS 4096     /* reina_day_t.day < 4096: winner-selection keys carry the day in 12 bits and are never
                                    cleared (the reference's default scenario runs 565 days, variables.py:233) */
 #define REINA_PRESSURE_WORDS (REINA_MAX_SHARDS * REINA_MAX_RANGES * REINA_MAX_VARIANTS)
+/* The block a sharded population all-reduces once per day (buffers.pressure) = the REINA_PRESSURE_WORDS above followed by
+ * every shard's BED / ICU EVENT MAPS: shard s writes, for each of its R priority buckets of the day's bed / ICU events, the
+ * composed saturating map of that bucket's events (free beds, free units before -> after; 64 bits, two int32 words:
+ * csrc/reina_prims.h rp_sat_pack) into segment s and zeros elsewhere, so that the sum is the table of all shards' maps.
+ * With it every shard walks its own events against ONE pool of beds and ICU units, in the global order (bucket, shard,
+ * priority, agent): exact pooled capacity (the reference hands beds out of one counter,
+ * main.pyx:617-651).  R must be the same on every shard: reina_config_t.hosp_ranges. */
+#define REINA_EXCHANGE_WORDS(n_shards, hosp_ranges) \
+    ((size_t)REINA_PRESSURE_WORDS + ((n_shards) > 1 ? (size_t)(n_shards) * 2u * (size_t)(hosp_ranges) : 0u))
 #define REINA_MIRROR_CELLS (REINA_MAX_RANGES * REINA_MAX_VARIANTS)
 /* sharded populations: the four pressure words of contact range REINA_MAX_RANGES - 1 (never a real range: a
  * sharded engine accepts at most REINA_MAX_RANGES - 1) carry each shard's free beds / free ICU units at day open and
- * its demand of the day (admission / ICU-transfer requests) through the same all-reduce; every shard then takes its
- * demand-proportional share of the pooled free capacity before it walks its bed / ICU events (rp_capacity_share) */
+ * its demand of the day (admission / ICU-transfer requests) through the same all-reduce: their sums are the ONE pool
+ * the day's events of all shards are walked against, and decide -- for all shards alike -- whether a resource can run
+ * out today (whether the events' order matters) */
 #define REINA_PRESSURE_FREE_BEDS(rank) (((rank) * REINA_MAX_RANGES + (REINA_MAX_RANGES - 1)) * REINA_MAX_VARIANTS)
 #define REINA_PRESSURE_FREE_ICU(rank) (REINA_PRESSURE_FREE_BEDS(rank) + 1)
 #define REINA_PRESSURE_DEMAND_BEDS(rank) (REINA_PRESSURE_FREE_BEDS(rank) + 2)
@@ -100,6 +110,7 @@ enum {
                                                            above they say whether a resource can run out today, i.e. whether event ORDER matters */
     REINA_L_WALK_TICKET,                                /* a large population's ordered event walk: the next priority bucket to be handed out
                                                            (zeroed by the day's opening) */
+    REINA_L_SORT_TICKET,                                /* the same for a sharded population's pre-sort of its event buckets */
     REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_DET_SIDE = 48,                              /* [REINA_MAX_AGES] the day's detections by age from the test queue (the day's opening
                                                            launch), folded into the counters by the day's last launch */
@@ -124,16 +135,22 @@ static inline uint32_t REINA_HOSP_RANGES(uint32_t n_agents) {
     while (r < REINA_HOSP_MAX_RANGES && (uint64_t)r * 65536u < n_agents) r <<= 1;
     return r;
 }
-static inline uint32_t REINA_HOSP_BUCKET_CAP(uint32_t n_agents, uint32_t max_hosp_events) {
+static inline uint32_t REINA_HOSP_BUCKET_CAP_R(uint32_t ranges, uint32_t max_hosp_events) {
     const uint32_t cap = max_hosp_events > REINA_MAX_HOSP_EVENTS ? max_hosp_events : REINA_MAX_HOSP_EVENTS;
-    return 2u * (cap / REINA_HOSP_RANGES(n_agents)) + 64u;   /* twice the mean at the day capacity: > 10 sigma */
+    return 2u * (cap / ranges) + 64u;   /* twice the mean at the day capacity: > 10 sigma */
+}
+static inline uint32_t REINA_HOSP_BUCKET_CAP(uint32_t n_agents, uint32_t max_hosp_events) {
+    return REINA_HOSP_BUCKET_CAP_R(REINA_HOSP_RANGES(n_agents), max_hosp_events);
 }
 static inline uint32_t REINA_HOSP_MAX_EVENTS_FOR(uint32_t n_agents) {   /* the largest max_hosp_events reina_create accepts */
     return ((REINA_HOSP_MAX_BUCKET_KEYS - 64u) / 2u) * REINA_HOSP_RANGES(n_agents);
 }
+static inline size_t REINA_HOSP_EVENT_WORDS_R(uint32_t ranges, uint32_t max_hosp_events) {   /* (reina_config_t.hosp_ranges given) */
+    const size_t r = ranges;
+    return r / 2 + 2 * r + r * (size_t)REINA_HOSP_BUCKET_CAP_R(ranges, max_hosp_events);
+}
 static inline size_t REINA_HOSP_EVENT_WORDS(uint32_t n_agents, uint32_t max_hosp_events) {
-    const size_t r = REINA_HOSP_RANGES(n_agents);
-    return r / 2 + 2 * r + r * (size_t)REINA_HOSP_BUCKET_CAP(n_agents, max_hosp_events);
+    return REINA_HOSP_EVENT_WORDS_R(REINA_HOSP_RANGES(n_agents), max_hosp_events);
 }
 
 typedef struct {
@@ -151,6 +168,9 @@ typedef struct {
     uint32_t n_shards;        /* G >= 1: the population is split over G engine instances (ranks) */
     uint32_t shard_rank;      /* this instance's rank in [0, G) */
     uint32_t mirror_slots;    /* power of two: slots per (range, variant) cell of buffers.mirror */
+    uint32_t hosp_ranges;     /* 0: REINA_HOSP_RANGES(n_agents); a sharded population passes the SAME power of two (16 ..
+                                 REINA_HOSP_MAX_RANGES) on every shard, e.g. REINA_HOSP_RANGES of its largest shard: the
+                                 shards exchange per-bucket maps of the day's bed / ICU events */
     int32_t age_start[REINA_MAX_AGES + 1]; /* first agent index of each age; [A] = n_agents
                                               (Population.age_start, main.pyx:1332,1442) */
 } reina_config_t;
@@ -238,7 +258,7 @@ typedef struct {
     uint32_t *queue1;         /* [max_queue] testing queue, odd days */
     uint32_t *level1;         /* [max_queue] contact-tracing level-1 work list */
     uint64_t *hosp_events;    /* [REINA_HOSP_EVENT_WORDS(n_agents, max_hosp_events)]: the day's bed / ICU events by priority range */
-    int32_t *pressure;        /* [REINA_PRESSURE_WORDS] cross-shard infection pressure of the day:
+    int32_t *pressure;        /* [REINA_EXCHANGE_WORDS(n_shards, hosp_ranges)] cross-shard infection pressure of the day:
                                  [dest shard][contact range][variant] = transmissible contacts aimed at
                                  agents of another shard. Filled by reina_step_day_begin, summed over
                                  shards by the caller (one all-reduce), consumed by reina_step_day_end */
@@ -329,7 +349,7 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream);
 /* In-stream collective for a sharded population: `allreduce` has the signature of RCCL's
  * ncclAllReduce (sendbuff, recvbuff, count, datatype, op, comm, stream) and is called by
  * reina_step_day / reina_run_days* between the two halves of every day as
- * allreduce(pressure, pressure, REINA_PRESSURE_WORDS, 2 = ncclInt32, 0 = ncclSum, comm, stream), i.e.
+ * allreduce(pressure, pressure, REINA_EXCHANGE_WORDS(n_shards, hosp_ranges), 2 = ncclInt32, 0 = ncclSum, comm, stream), i.e.
  * on the day stream itself: no host round trip, no second stream.  The library does not link RCCL;
  * the caller hands in the function and its communicator (NULL, NULL switches it off). */
 typedef int (*reina_allreduce_fn)(const void *sendbuff, void *recvbuff, size_t count, int datatype, int op,

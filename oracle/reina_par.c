@@ -40,6 +40,7 @@ typedef struct {
     int32_t range_min[REINA_MAX_RANGES], range_max[REINA_MAX_RANGES];
     float psus_max[REINA_MAX_VARIANTS];
     uint32_t cthr[REINA_MAX_AGES][REINA_COUNT_WORDS];   /* contact-count thresholds of every age (reina_contacts.h) */
+    uint32_t hosp_ranges, hosp_range_bits;              /* priority buckets of the day's bed / ICU events (sharded: exchanged maps) */
     reina_allreduce_fn coll_fn;
     void *coll_comm;
 } Par;
@@ -95,6 +96,8 @@ int par_create(const reina_config_t *cfg, const reina_disease_t *disease, Par **
         free(e);
         return REINA_E_INVALID;
     }
+    e->hosp_ranges = cfg->hosp_ranges ? cfg->hosp_ranges : REINA_HOSP_RANGES(cfg->n_agents);
+    while ((1u << e->hosp_range_bits) < e->hosp_ranges) e->hosp_range_bits++;
     uint64_t seed = rp_shard_seed(cfg->seed, e->cfg.shard_rank);
     e->k0 = (uint32_t)seed;
     e->k1 = (uint32_t)(seed >> 32);
@@ -588,63 +591,146 @@ static void run_hospital(Par *e, const reina_day_t *dp) {
     run_hospital_events(e, dp);
 }
 
+/* one event applied to its agent; *b, *c: free beds / ICU units, moved as the reference's counters move */
+static void apply_hospital_event(Par *e, const reina_day_t *dp, uint64_t ev, int *b, int *c) {
+    const reina_disease_t *d = &e->dis;
+    int type = (int)(ev & 3);
+    uint32_t i = (uint32_t)((ev >> 2) & 0xFFFFFFFFu);
+    uint32_t w = e->buf.hot[i];
+    int age = age_of(e, i), v = RH_VARIANT(w), sev = RH_SEV(w);
+    float od = e->buf.cold[i].onset_days;
+    if (type == EV_HOSPITALIZE) {
+        if (!(w & RH_DETECTED)) {
+            w |= RH_DETECTED;
+            CNT(e, REINA_C_DETECTED, age) += 1;
+            CNT(e, REINA_C_ALL_DETECTED, age) += 1;
+        }
+        if (*b == 0) {
+            w = dies_in_hospital(e, i, dp->day, sev, v, 0) ? do_die(e, w, age) : do_recover(e, w, age);
+        } else {
+            (*b)--;
+            const float f = rp_ward_stay(sev, od, d->ratio_of_duration_before_hospitalisation[v], d->ratio_of_duration_in_ward[v]);
+            w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)), dp->day);
+            CNT(e, REINA_C_HOSPITALIZED, age) += 1;
+            CNT(e, REINA_C_IN_WARD, age) += 1;
+        }
+    } else if (type == EV_TO_ICU) {
+        (*b)++;
+        int ok = *c > 0;
+        if (ok) (*c)--;
+        if (!ok && dies_in_hospital(e, i, dp->day, sev, v, 0)) {
+            CNT(e, REINA_C_IN_WARD, age) -= 1;
+            CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
+            w = do_die(e, w, age);
+        } else {
+            const float f = rp_icu_stay(sev, od, d->ratio_of_duration_before_hospitalisation[v], d->ratio_of_duration_in_ward[v]);
+            w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)), dp->day);
+            CNT(e, REINA_C_IN_WARD, age) -= 1;
+            CNT(e, REINA_C_IN_ICU, age) += 1;
+            CNT(e, REINA_C_CUM_ICU, age) += 1;
+        }
+    } else if (type == EV_RELEASE_WARD) {
+        CNT(e, REINA_C_IN_WARD, age) -= 1;
+        CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
+        (*b)++;
+        w = dies_in_hospital(e, i, dp->day, sev, v, 1) ? do_die(e, w, age) : do_recover(e, w, age);
+    } else {
+        CNT(e, REINA_C_IN_ICU, age) -= 1;
+        CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
+        (*c)++;
+        w = dies_in_hospital(e, i, dp->day, sev, v, 1) ? do_die(e, w, age) : do_recover(e, w, age);
+    }
+    e->buf.hot[i] = w;
+}
+
+/* the map of one event on the free beds / free ICU units (reina_prims.h: rp_sat_t) */
+static rp_sat_t bed_map(int type) {
+    rp_sat_t f = rp_sat_id();
+    if (type == EV_HOSPITALIZE) { f.a = -1; f.m = 0; }
+    else if (type == EV_TO_ICU || type == EV_RELEASE_WARD) f.a = 1;
+    return f;
+}
+static rp_sat_t icu_map(int type) {
+    rp_sat_t f = rp_sat_id();
+    if (type == EV_TO_ICU) { f.a = -1; f.m = 0; }
+    else if (type == EV_RELEASE_ICU) f.a = 1;
+    return f;
+}
+static uint32_t event_bucket(const Par *e, uint64_t ev) { return (uint32_t)(ev >> 34) >> (20u - e->hosp_range_bits); }
+static uint64_t *exchange_maps(Par *e, uint32_t shard) {
+    return (uint64_t *)(e->buf.pressure + REINA_PRESSURE_WORDS) + (size_t)shard * e->hosp_ranges;
+}
+
+/* a SHARDED population, first half of the day: the day's events sorted, every priority bucket's composed map into this
+ * shard's segment of the exchange block (include/reina_hip.h: REINA_EXCHANGE_WORDS) */
+static void publish_hospital_maps(Par *e) {
+    int M = CTL(e, REINA_L_HOSP);
+    qsort(e->buf.hosp_events, (size_t)M, sizeof(uint64_t), cmp_u64);
+    uint64_t *seg = exchange_maps(e, e->cfg.shard_rank);
+    for (int k = 0; k < M;) {
+        const uint32_t bk = event_bucket(e, e->buf.hosp_events[k]);
+        rp_sat_t fb = rp_sat_id(), fc = rp_sat_id();
+        for (; k < M && event_bucket(e, e->buf.hosp_events[k]) == bk; k++) {
+            const int type = (int)(e->buf.hosp_events[k] & 3);
+            fb = rp_sat_then(fb, bed_map(type));
+            fc = rp_sat_then(fc, icu_map(type));
+        }
+        seg[bk] = rp_sat_pack(fb, fc);
+    }
+}
+
 static void run_hospital_events(Par *e, const reina_day_t *dp) {
     int M = CTL(e, REINA_L_HOSP);
+    if (e->cfg.n_shards > 1) {
+        /* ONE pool of beds / ICU units for all shards (the reference: one counter, main.pyx:617-651).  The all-reduce has
+         * brought every shard's free counts at day open, its demand, and the map of every priority bucket of its events.
+         * Global order of the day's events: (priority bucket, shard, priority, agent) -- this shard walks its own events
+         * and lets the other shards' buckets act on the pool through their maps. */
+        int64_t fb = 0, fc = 0, db = 0, dc = 0;
+        for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+            fb += e->buf.pressure[REINA_PRESSURE_FREE_BEDS(sh)];
+            fc += e->buf.pressure[REINA_PRESSURE_FREE_ICU(sh)];
+            db += e->buf.pressure[REINA_PRESSURE_DEMAND_BEDS(sh)];
+            dc += e->buf.pressure[REINA_PRESSURE_DEMAND_ICU(sh)];
+        }
+        int b = (int)fb, c = (int)fc;
+        int own_b = 0, own_c = 0;   /* the pool's net change by this shard's events */
+        if (fb >= db && fc >= dc) {
+            /* nothing can run out anywhere: every request granted */
+            for (int k = 0; k < M; k++) {
+                int b0 = b, c0 = c;
+                apply_hospital_event(e, dp, e->buf.hosp_events[k], &b, &c);
+                own_b += b - b0;
+                own_c += c - c0;
+            }
+        } else {
+            int k = 0;
+            for (uint32_t bk = 0; bk < e->hosp_ranges; bk++)
+                for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+                    if (sh != e->cfg.shard_rank) {
+                        rp_sat_t gb, gc;
+                        rp_sat_unpack(exchange_maps(e, sh)[bk], &gb, &gc);
+                        b = rp_sat_apply(gb, b);
+                        c = rp_sat_apply(gc, c);
+                        continue;
+                    }
+                    for (; k < M && event_bucket(e, e->buf.hosp_events[k]) == bk; k++) {
+                        int b0 = b, c0 = c;
+                        apply_hospital_event(e, dp, e->buf.hosp_events[k], &b, &c);
+                        own_b += b - b0;
+                        own_c += c - c0;
+                    }
+                }
+        }
+        SC(e, REINA_S_AVAILABLE_BEDS) += own_b;
+        SC(e, REINA_S_AVAILABLE_ICU) += own_c;
+        return;
+    }
     if (!M) return;
     int b = SC(e, REINA_S_AVAILABLE_BEDS), c = SC(e, REINA_S_AVAILABLE_ICU);
     if (!(b >= CTL(e, REINA_L_HOSP_ADMIT) && c >= CTL(e, REINA_L_ICU_ADMIT)))
         qsort(e->buf.hosp_events, (size_t)M, sizeof(uint64_t), cmp_u64);
-    const reina_disease_t *d = &e->dis;
-    for (int k = 0; k < M; k++) {
-        uint64_t ev = e->buf.hosp_events[k];
-        int type = (int)(ev & 3);
-        uint32_t i = (uint32_t)((ev >> 2) & 0xFFFFFFFFu);
-        uint32_t w = e->buf.hot[i];
-        int age = age_of(e, i), v = RH_VARIANT(w), sev = RH_SEV(w);
-        float od = e->buf.cold[i].onset_days;
-        if (type == EV_HOSPITALIZE) {
-            if (!(w & RH_DETECTED)) {
-                w |= RH_DETECTED;
-                CNT(e, REINA_C_DETECTED, age) += 1;
-                CNT(e, REINA_C_ALL_DETECTED, age) += 1;
-            }
-            if (b == 0) {
-                w = dies_in_hospital(e, i, dp->day, sev, v, 0) ? do_die(e, w, age) : do_recover(e, w, age);
-            } else {
-                b--;
-                const float f = rp_ward_stay(sev, od, d->ratio_of_duration_before_hospitalisation[v], d->ratio_of_duration_in_ward[v]);
-                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_HOSPITALIZED), clamp_days(e, rp_round_to_int(f)), dp->day);
-                CNT(e, REINA_C_HOSPITALIZED, age) += 1;
-                CNT(e, REINA_C_IN_WARD, age) += 1;
-            }
-        } else if (type == EV_TO_ICU) {
-            b++;
-            int ok = c > 0;
-            if (ok) c--;
-            if (!ok && dies_in_hospital(e, i, dp->day, sev, v, 0)) {
-                CNT(e, REINA_C_IN_WARD, age) -= 1;
-                CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
-                w = do_die(e, w, age);
-            } else {
-                const float f = rp_icu_stay(sev, od, d->ratio_of_duration_before_hospitalisation[v], d->ratio_of_duration_in_ward[v]);
-                w = RH_SET_DAYS_LEFT(RH_SET_STATE(w, RS_IN_ICU), clamp_days(e, rp_round_to_int(f)), dp->day);
-                CNT(e, REINA_C_IN_WARD, age) -= 1;
-                CNT(e, REINA_C_IN_ICU, age) += 1;
-                CNT(e, REINA_C_CUM_ICU, age) += 1;
-            }
-        } else if (type == EV_RELEASE_WARD) {
-            CNT(e, REINA_C_IN_WARD, age) -= 1;
-            CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
-            b++;
-            w = dies_in_hospital(e, i, dp->day, sev, v, 1) ? do_die(e, w, age) : do_recover(e, w, age);
-        } else {
-            CNT(e, REINA_C_IN_ICU, age) -= 1;
-            CNT(e, REINA_C_HOSPITALIZED, age) -= 1;
-            c++;
-            w = dies_in_hospital(e, i, dp->day, sev, v, 1) ? do_die(e, w, age) : do_recover(e, w, age);
-        }
-        e->buf.hot[i] = w;
-    }
+    for (int k = 0; k < M; k++) apply_hospital_event(e, dp, e->buf.hosp_events[k], &b, &c);
     SC(e, REINA_S_AVAILABLE_BEDS) = b;
     SC(e, REINA_S_AVAILABLE_ICU) = c;
 }
@@ -973,7 +1059,7 @@ int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
     CTL(e, REINA_L_CONTACTS) = 0;
     CTL(e, REINA_L_HOSP_ADMIT) = 0;
     CTL(e, REINA_L_ICU_ADMIT) = 0;
-    memset(e->buf.pressure, 0, sizeof(int32_t) * REINA_PRESSURE_WORDS);
+    memset(e->buf.pressure, 0, sizeof(int32_t) * REINA_EXCHANGE_WORDS(e->cfg.n_shards, e->hosp_ranges));
     run_imports(e, dp, 0, &import_base);
     run_testing(e, dp);
     run_vaccinations(e, dp);
@@ -986,6 +1072,7 @@ int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
         e->buf.pressure[REINA_PRESSURE_FREE_ICU(e->cfg.shard_rank)] = free_icu_open;
         e->buf.pressure[REINA_PRESSURE_DEMAND_BEDS(e->cfg.shard_rank)] = CTL(e, REINA_L_HOSP_ADMIT);
         e->buf.pressure[REINA_PRESSURE_DEMAND_ICU(e->cfg.shard_rank)] = CTL(e, REINA_L_ICU_ADMIT);
+        publish_hospital_maps(e);
     }
     return 0;
 }
@@ -993,13 +1080,6 @@ int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
 /* second half: after the caller has summed `pressure` over the shards */
 int par_step_day_end(Par *e, const reina_day_t *dp, void *stream) {
     (void)stream;
-    if (e->cfg.n_shards > 1) {
-        /* this shard's share of the pooled free beds / ICU units, in proportion to today's demand */
-        SC(e, REINA_S_AVAILABLE_BEDS) = rp_capacity_share(e->buf.pressure, e->cfg.n_shards, e->cfg.shard_rank, REINA_PRESSURE_FREE_BEDS(0),
-                                                          REINA_MAX_RANGES * REINA_MAX_VARIANTS, 0, 2);
-        SC(e, REINA_S_AVAILABLE_ICU) = rp_capacity_share(e->buf.pressure, e->cfg.n_shards, e->cfg.shard_rank, REINA_PRESSURE_FREE_BEDS(0),
-                                                         REINA_MAX_RANGES * REINA_MAX_VARIANTS, 1, 3);
-    }
     run_remote(e, dp);     /* (a stand-in source's infectee-list flag: its word before the day's bed / ICU walk) */
     run_hospital(e, dp);
     run_install(e, dp);
@@ -1015,7 +1095,8 @@ int par_set_collective(Par *e, reina_allreduce_fn fn, void *comm) {
 int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
     int rc = par_step_day_begin(e, dp, stream);
     if (rc) return rc;
-    if (e->coll_fn && e->coll_fn(e->buf.pressure, e->buf.pressure, REINA_PRESSURE_WORDS, 2, 0, e->coll_comm, stream) != 0)
+    if (e->coll_fn && e->coll_fn(e->buf.pressure, e->buf.pressure, REINA_EXCHANGE_WORDS(e->cfg.n_shards, e->hosp_ranges), 2, 0, e->coll_comm,
+                                 stream) != 0)
         return REINA_E_INVALID;
     return par_step_day_end(e, dp, stream);
 }

@@ -276,11 +276,18 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     }
     e->h_params.max_queue = cfg->max_queue;
     e->h_params.max_hosp_events = cfg->max_hosp_events > REINA_MAX_HOSP_EVENTS ? cfg->max_hosp_events : REINA_MAX_HOSP_EVENTS;
-    e->h_params.hosp_ranges = REINA_HOSP_RANGES(cfg->n_agents);
+    e->h_params.hosp_ranges = cfg->hosp_ranges ? cfg->hosp_ranges : REINA_HOSP_RANGES(cfg->n_agents);
+    if (e->h_params.hosp_ranges < 16 || e->h_params.hosp_ranges > REINA_HOSP_MAX_RANGES || (e->h_params.hosp_ranges & (e->h_params.hosp_ranges - 1))) {
+        g_last_error = "hosp_ranges must be a power of two in [16, REINA_HOSP_MAX_RANGES]";
+        delete e;
+        return REINA_E_INVALID;
+    }
     e->h_params.hosp_range_bits = 0;
     while ((1u << e->h_params.hosp_range_bits) < e->h_params.hosp_ranges) e->h_params.hosp_range_bits++;
-    e->h_params.hosp_bucket_cap = REINA_HOSP_BUCKET_CAP(cfg->n_agents, cfg->max_hosp_events);
-    e->h_params.hosp_parallel = cfg->n_agents > REINA_HOSP_SMALL_AGENTS ? 1u : 0u;
+    e->h_params.hosp_bucket_cap = REINA_HOSP_BUCKET_CAP_R(e->h_params.hosp_ranges, cfg->max_hosp_events);
+    // (a sharded population always takes the bucket-per-wave walk: its shards exchange per-bucket maps)
+    e->h_params.hosp_parallel = (cfg->n_agents > REINA_HOSP_SMALL_AGENTS || e->cfg.n_shards > 1) ? 1u : 0u;
+    e->exchange_words = (uint32_t)REINA_EXCHANGE_WORDS(e->cfg.n_shards, e->h_params.hosp_ranges);
     if (e->h_params.hosp_parallel && e->h_params.hosp_bucket_cap > REINA_HOSP_MAX_BUCKET_KEYS) {
         g_last_error = "max_hosp_events too large for this population: a bucket of the event walk holds at most 4096 keys "
                        "(pass at most REINA_HOSP_MAX_EVENTS_FOR(n_agents), include/reina_hip.h)";
@@ -296,6 +303,8 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
                                      (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_presort<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)((size_t)HOSP_P_THREADS * HOSP_P_E * 8)), free_engine(e));
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)((size_t)REINA_MAX_HOSP_EVENTS * 8)), free_engine(e));
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -541,6 +550,11 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows);
     }
     e->cur_scan_waves = day_blocks * DAY_WAVES;   // (the day's later launches walk the per-wave slices)
+    if (e->cfg.n_shards > 1) {
+        // a sharded population: its event buckets sorted and their maps written to the exchange block BEFORE the all-reduce
+        const uint32_t n_walk = (e->h_params.hosp_ranges + 15u) / 16u;
+        LAUNCH_DAY(e, today, REINA_PK_HOSP_SORT, k_hosp_presort, dim3(n_walk, K), dim3(HOSP_THREADS), (size_t)HOSP_P_THREADS * HOSP_P_E * 8, s, dp);
+    }
     (void)scan_tiles;
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
@@ -612,7 +626,7 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
     if (rc) return rc;
     if (e->coll_fn) {
         // the only per-day exchange of a sharded population, queued on the day stream itself
-        const int r = e->coll_fn(e->buf.pressure, e->buf.pressure, REINA_PRESSURE_WORDS, 2 /* ncclInt32 */, 0 /* ncclSum */,
+        const int r = e->coll_fn(e->buf.pressure, e->buf.pressure, e->exchange_words, 2 /* ncclInt32 */, 0 /* ncclSum */,
                                  e->coll_comm, stream);
         if (r != 0) {
             g_last_error = "collective failed with code " + std::to_string(r);

@@ -320,30 +320,50 @@ RP_HD uint32_t rp_priority20(uint32_t k0, uint32_t k1, uint32_t who, uint32_t da
 RP_HD uint64_t rp_shard_seed(uint64_t seed, uint32_t rank) {
     return seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;
 }
-// Sharded populations: the free beds (ICU units) of ALL shards at day open are re-divided every day in proportion to
-// the day's demand (admission / transfer requests), so that capacity goes where the patients are: a shard's share of
-// T = sum of free units is floor(T * d[rank] / D), the first T - sum(floors) shards with demand get one more.
-// `words` = the all-reduced pressure block; shard s keeps its free count at words[first + s * stride + k_free] and
-// its demand at [... + k_dem].  No demand anywhere (or a negative pool): everyone keeps what it has.
-RP_HD int32_t rp_capacity_share(const int32_t *words, uint32_t n_shards, uint32_t rank, uint32_t first, uint32_t stride,
-                                uint32_t k_free, uint32_t k_dem) {
-    int64_t T = 0, D = 0;
-    for (uint32_t s = 0; s < n_shards; s++) {
-        T += words[first + s * stride + k_free];
-        D += words[first + s * stride + k_dem];
+// ------------------------------------------------------------------ saturating maps of the bed / ICU walk
+// Every bed / ICU event acts on a free count x as f(x) = max(x + a, m): an admission (a = -1, m = 0), a release (a = +1,
+// m = "never binds").  Such maps compose to the same form -- (a1, m1) then (a2, m2) = (a1 + a2, max(m1 + a2, m2)) -- so
+// the free count in front of any event of an ORDERED walk is a prefix composition (k_hospital.inc), and a whole bucket of
+// events is ONE map: what a sharded population's shards exchange (include/reina_hip.h: REINA_EXCHANGE_WORDS).
+typedef struct { int a, m; } rp_sat_t;
+#define RP_SAT_NEG (-(1 << 29))
+RP_HD rp_sat_t rp_sat_id(void) {
+    rp_sat_t f;
+    f.a = 0;
+    f.m = RP_SAT_NEG;
+    return f;
+}
+RP_HD rp_sat_t rp_sat_then(rp_sat_t f, rp_sat_t g) {   // f first, then g
+    rp_sat_t r;
+    r.a = f.a + g.a;
+    int t = f.m + g.a;
+    if (t < RP_SAT_NEG) t = RP_SAT_NEG;
+    r.m = t > g.m ? t : g.m;
+    return r;
+}
+RP_HD int rp_sat_apply(rp_sat_t f, int x) {
+    int y = x + f.a;
+    return y > f.m ? y : f.m;
+}
+// the bed map and the ICU map of a bucket in 57 bits: a and m of either lie in [-4096, 4096] (a bucket holds at most 4096
+// keys), m may also be "never binds" (<= RP_SAT_NEG / 2); bit 63 = present (a zero word reads as "no events": identity)
+RP_HD uint64_t rp_sat_pack(rp_sat_t fb, rp_sat_t fc) {
+    const uint64_t ba = (uint64_t)(fb.a + 8192) & 0x3FFFu, ca = (uint64_t)(fc.a + 8192) & 0x3FFFu;
+    const uint64_t bm = fb.m <= RP_SAT_NEG / 2 ? 0x3FFFull : ((uint64_t)(fb.m + 8192) & 0x3FFFu);
+    const uint64_t cm = fc.m <= RP_SAT_NEG / 2 ? 0x3FFFull : ((uint64_t)(fc.m + 8192) & 0x3FFFu);
+    return (1ull << 63) | ba | (bm << 14) | (ca << 28) | (cm << 42);
+}
+RP_HD void rp_sat_unpack(uint64_t v, rp_sat_t *fb, rp_sat_t *fc) {
+    if (!(v >> 63)) {
+        *fb = rp_sat_id();
+        *fc = rp_sat_id();
+        return;
     }
-    const int32_t own = words[first + rank * stride + k_free];
-    if (D <= 0 || T < 0) return own;
-    int64_t given = 0;
-    for (uint32_t s = 0; s < n_shards; s++) given += T * words[first + s * stride + k_dem] / D;
-    int64_t extra = T - given;   // < number of shards with demand
-    int64_t mine = T * words[first + rank * stride + k_dem] / D;
-    for (uint32_t s = 0; s <= rank && extra > 0; s++)
-        if (words[first + s * stride + k_dem] > 0) {
-            if (s == rank) mine += 1;
-            extra--;
-        }
-    return (int32_t)mine;
+    const uint32_t bm = (uint32_t)(v >> 14) & 0x3FFFu, cm = (uint32_t)(v >> 42) & 0x3FFFu;
+    fb->a = (int)((uint32_t)v & 0x3FFFu) - 8192;
+    fb->m = bm == 0x3FFFu ? RP_SAT_NEG : (int)bm - 8192;
+    fc->a = (int)((uint32_t)(v >> 28) & 0x3FFFu) - 8192;
+    fc->m = cm == 0x3FFFu ? RP_SAT_NEG : (int)cm - 8192;
 }
 
 // candidate "source id" of an infection realised from cross-shard pressure (no local infector)

@@ -66,7 +66,7 @@ class Config(ctypes.Structure):
                 ('seed', ctypes.c_uint64),
                 ('max_work_items', ctypes.c_uint32), ('max_candidates', ctypes.c_uint32),
                 ('max_queue', ctypes.c_uint32), ('n_shards', ctypes.c_uint32),
-                ('shard_rank', ctypes.c_uint32), ('mirror_slots', ctypes.c_uint32),
+                ('shard_rank', ctypes.c_uint32), ('mirror_slots', ctypes.c_uint32), ('hosp_ranges', ctypes.c_uint32),
                 ('age_start', ctypes.c_int32 * (MAX_AGES + 1))]
 
 
@@ -144,9 +144,9 @@ def hosp_ranges(n_agents):
     return r
 
 
-def hosp_bucket_cap(n_agents, max_hosp_events):
-    """include/reina_hip.h: REINA_HOSP_BUCKET_CAP"""
-    return 2 * (max(MAX_HOSP_EVENTS, max_hosp_events) // hosp_ranges(n_agents)) + 64
+def hosp_bucket_cap(n_agents, max_hosp_events, ranges=0):
+    """include/reina_hip.h: REINA_HOSP_BUCKET_CAP(_R); `ranges`: reina_config_t.hosp_ranges when given"""
+    return 2 * (max(MAX_HOSP_EVENTS, max_hosp_events) // (ranges or hosp_ranges(n_agents))) + 64
 
 
 def default_max_hosp_events(n_agents):
@@ -158,10 +158,16 @@ def default_max_hosp_events(n_agents):
     return max(MAX_HOSP_EVENTS, min(n_agents // 128, per_bucket * hosp_ranges(n_agents)))
 
 
-def hosp_event_words(n_agents, max_hosp_events):
-    """include/reina_hip.h: REINA_HOSP_EVENT_WORDS (64-bit words of buffers.hosp_events)"""
-    r = hosp_ranges(n_agents)
-    return r // 2 + 2 * r + r * hosp_bucket_cap(n_agents, max_hosp_events)
+def hosp_event_words(n_agents, max_hosp_events, ranges=0):
+    """include/reina_hip.h: REINA_HOSP_EVENT_WORDS(_R) (64-bit words of buffers.hosp_events)"""
+    r = ranges or hosp_ranges(n_agents)
+    return r // 2 + 2 * r + r * hosp_bucket_cap(n_agents, max_hosp_events, r)
+
+
+def exchange_words(n_shards, ranges):
+    """include/reina_hip.h: REINA_EXCHANGE_WORDS -- int32 words of buffers.pressure = what a sharded population all-reduces
+    once per day: the infection-pressure block + every shard's table of bed / ICU event maps"""
+    return PRESSURE_WORDS + (n_shards * 2 * ranges if n_shards > 1 else 0)
 
 
 def bind_abi(lib, prefix):
@@ -324,8 +330,8 @@ class Engine:
             queue0=a.zeros(config.max_queue, np.uint32), queue1=a.zeros(config.max_queue, np.uint32),
             level1=a.zeros(config.max_queue, np.uint32),
             # the day's bed / ICU events by priority range: [bucket counts][bucket aggregates][keys]
-            hosp_events=a.zeros(hosp_event_words(n, config.max_hosp_events), np.uint64),
-            pressure=a.zeros(PRESSURE_WORDS, np.int32),
+            hosp_events=a.zeros(hosp_event_words(n, config.max_hosp_events, config.hosp_ranges), np.uint64),
+            pressure=a.zeros(exchange_words(config.n_shards, config.hosp_ranges or hosp_ranges(n)), np.int32),
             mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 32, np.uint64),
             mirror_meta=a.zeros(2 * MAX_RANGES * MAX_VARIANTS, np.uint32),
             work_counts=a.zeros(5 * MAX_SCAN_WAVES, np.uint32),

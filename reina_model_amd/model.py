@@ -292,6 +292,11 @@ class Context:
         cfg.max_hosp_events = _eng.default_max_hosp_events(total)   # bed / ICU events of one day (clamped to what the walk's buckets hold)
         cfg.n_shards = self.n_shards
         cfg.shard_rank = self.shard_rank
+        if self.n_shards > 1:
+            # the shards exchange per-bucket maps of the day's bed / ICU events: the same number of buckets on every shard
+            # (that of the largest shard: every age's count divided by the shards, rounded up)
+            largest = int(sum(-(-int(c) // self.n_shards) for c in self.global_age_counts))
+            cfg.hosp_ranges = _eng.hosp_ranges(largest)
         slots = 64
         while slots < total // 1024 and slots < (1 << 20):
             slots <<= 1

@@ -68,8 +68,9 @@ def test_oracle_b_matches_sequential_oracle_statistically():
 @pytest.mark.parametrize('G', [4, 8])
 def test_sharded_formulation_matches_sequential_oracle_statistically(G):
     """SURVEY 8e deviation check: the population split over G shards (4, and the 8 of a full node) with import /
-    vaccination quotas partitioned, free beds / ICU units pooled and re-divided by demand every day, and cross-shard
-    contacts exchanged as pressure histograms stays inside the same tolerance (12 seeds)."""
+    vaccination quotas partitioned, beds / ICU units handed out of ONE pool in a global order of the day's events, and
+    cross-shard contacts exchanged as pressure histograms stays inside the same tolerance (12 seeds) -- every quantity,
+    the saturated ward included."""
     import sys
     sys.path.insert(0, GOLDEN)
     import make_ensemble as me
@@ -91,20 +92,12 @@ def test_sharded_formulation_matches_sequential_oracle_statistically(G):
                 out[d, k] = c[i * A:(i + 1) * A].sum()
             sharding.step_shards_together(ctxs)
         runs.append(out)
-    # Beds and ICU units: every shard takes its demand-proportional share of the pooled FREE capacity every day, so even
-    # 35 ICU units split 8 ways stay nearly as busy as the undivided pool (28 of 33 occupied before that).  What remains:
-    # a bed released during the day stays on its shard until the next morning's split.  Measured with 48 seeds
-    # (8 shards / sequential oracle, saturated ward of 300 beds): 0.984, 0.989, 0.986, 0.976 on days 60-90 and 0.967
-    # +- 0.004 on day 100, when the reference itself is leaving saturation (291 of 300) -- the same on the random
-    # stream before and after the contact draws moved to Philox2x32.  A 12-seed mean scatters +-0.8 % around that, so
-    # the bound here is 5 % (it was 3 %, set from a 12-seed sample that happened to land at 0.977).
+    # Beds and ICU units are ONE pool over all shards (the shards exchange the per-bucket maps of the day's bed / ICU events and
+    # every shard walks its own events in the global order): the saturated ward of 300 beds is as full as
+    # the sequential oracle's.  (Round 2 re-divided the free capacity every morning: 0.976-0.989 of it on days 60-90, 0.967
+    # on day 100, and this test exempted the saturated ward.)
     runs = np.array(runs)
-    ward = list(me.ATTRS).index('in_ward')
-    sat = lambda d, a, ref_mean: G == 8 and a == 'in_ward' and ref_mean > 0.95 * v['hospital_beds']
-    _check(runs, z, me.ATTRS, sat)
-    for d in DAYS_CHECKED:
-        if G == 8 and z['mean'][d, ward] > 0.95 * v['hospital_beds']:
-            assert runs[:, d, ward].mean() >= 0.95 * z['mean'][d, ward], (d, runs[:, d, ward].mean(), z['mean'][d, ward])
+    _check(runs, z, me.ATTRS)
 
 
 @pytest.mark.gpu

@@ -47,26 +47,21 @@ def test_negative_control_a_three_percent_bias_is_detected(what, factor):
 
 @pytest.mark.gpu
 def test_eight_shards_against_the_reference_distribution():
-    """SURVEY 8 f-4, measured instead of built: what do stand-in infectors (mirror attribution) and partitioned
-    capacity cost?  HUS x 365 d split over 8 shards (in-process on one GPU), 48 seeds, against the 128 reference runs
-    with the tolerance of ref_stats: everything that walks infector links -- `r`, `ct_cases_per_day`, detections --
-    and every epidemic curve is inside it; the only deviation is capacity at saturation (a unit released during the
-    day stays on its shard until the next morning's demand-proportional split): ICU occupancy runs about 3 % low."""
+    """SURVEY 8 f-4.  HUS x 365 d split over 8 shards (in-process on one GPU), 48 seeds, against the 128 runs of the REAL
+    reference with the tolerance of ref_stats -- EVERY series, no exemption: the epidemic curves and age-group cells,
+    everything that walks infector links (`r`, `ct_cases_per_day`, detections: stand-in infectors for cross-shard
+    infections), and the capacity series at saturation (beds and ICU units are one pool over the shards: round 2, which
+    re-divided the free capacity every morning, ran the saturated ICU 3.2 % low and this test exempted it)."""
     par, meta = ref_stats.run_sharded_ensemble('hus_default', range(90000, 90048), 8)
     ref, _ = ref_stats.load_ref('hus_default')
     rep = ref_stats.compare(par, ref, meta)
     print(ref_stats.tolerance_report(rep, meta))
-    capacity = ('in_icu', 'cum_icu', 'in_ward', 'available_icu_units', 'available_hospital_beds')
-    other = [f for f in rep['failures'] if not (any((' %s' % c) in f[0] or ('(%s)' % c) in f[0] for c in capacity))]
-    assert not other, other[:10]
+    assert not rep['failures'], rep['failures'][:10]
     zs = {m[0]: m for m in rep['means']}
     for d in ref['ck_days']:
-        for name in ('r', 'ct_cases_per_day', 'all_detected total', 'new_infections total'):
-            m = zs.get('day %d %s' % (d, name))
-            assert m is None or abs(m[1]) <= ref_stats.Z_MAX, m
         m = zs.get('day %d in_icu total' % d)
-        if m is not None and m[2] > 0.9 * 300:   # saturated in the reference: at most 5 % of the units idle here
-            assert m[3] >= 0.95 * m[2], m
+        if m is not None and m[2] > 0.9 * 300:   # saturated in the reference: as full here (1 % at most idle beyond it)
+            assert m[3] >= 0.99 * m[2], m
 
 
 @pytest.mark.slow
