@@ -16,3 +16,4 @@ for lo, hi in ((0, 118), (118, 200), (200, 365)):
     us = m / 100.0
     print('days %3d-%3d: opening until flag %.1f us/day, opening total %.1f, weekly-import workgroup %.1f | tracing workgroups: level0 loop mean %.1f (slowest ever %.1f, n=%d), wait %.1f, flush %.1f, level1 %.1f' % (
         lo, hi, us[5] / d, us[6] / d, us[9] / d, us[1] / max(1, m[25]), us[17], int(m[25]), us[2] / max(1, m[26]), us[3] / max(1, m[27]), us[4] / max(1, m[28])), flush=True)
+    print('      slowest wave ever, us since the block started -- level 0: queue entry read %.1f, its record / slots / word in %.1f, flags set %.1f, overflow list walked %.1f | level 1: %.1f %.1f %.1f %.1f' % tuple(us[40:48]), flush=True)
