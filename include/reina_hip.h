@@ -111,6 +111,8 @@ enum {
     REINA_L_WALK_TICKET,                                /* a large population's ordered event walk: the next priority bucket to be handed out
                                                            (zeroed by the day's opening) */
     REINA_L_SORT_TICKET,                                /* the same for a sharded population's pre-sort of its event buckets */
+    REINA_L_IMPORT_SYNC,                                /* [4] arrival words of the workgroups that share a day's weekly imports (zeroed by the
+                                                           day's last launch) */
     REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_DET_SIDE = 48,                              /* [REINA_MAX_AGES] the day's detections by age from the test queue (the day's opening
                                                            launch), folded into the counters by the day's last launch */

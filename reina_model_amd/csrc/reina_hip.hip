@@ -23,6 +23,7 @@
 #include <climits>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -227,6 +228,10 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 1)
             e->n_cus = (uint32_t)cus;
+        if (const char *w = std::getenv("REINA_IMPORT_WGS")) {
+            const int v = std::atoi(w);
+            if (v >= 1 && v <= 16) e->import_wgs = (uint32_t)v;
+        }
     }
     std::memset(&e->h_params, 0, sizeof(DevParams));
     std::memset(&e->h_tables, 0, sizeof(Tables));
@@ -520,7 +525,19 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     uint32_t n_pre = 0, n_post = 0;
     for (uint32_t b = 0; b < dp.n_import_batches; b++)
         (dp.import_batches[b].pre_init ? n_pre : n_post) += dp.import_batches[b].count;
-    const int weekly_own = n_pre == 0 && n_post > 0;   // (intervention imports share the claim keys: same workgroup then)
+    // weekly imports on a day without intervention imports (which would share their claim keys) have workgroups of their
+    // own: one per wave of imports, at most 16 (k_open.inc, imports_any); members of a group take one each (they wait on each
+    // other, and a group's launch is not resident as a whole)
+    // (> 0: so many workgroups for the weekly imports; <= 0: the opening workgroup places the day's imports, with -weekly_own
+    // helpers: open_role, k_testing.inc)
+    int weekly_own = n_pre == 0 && n_post > 0;
+    if (K == 1) {
+        const uint32_t most = n_pre > n_post ? n_pre : n_post;
+        int w = (int)((most + 511u) / 512u);
+        if (w > (int)e->import_wgs) w = (int)e->import_wgs;
+        if (weekly_own) weekly_own = w;
+        else if (n_pre > 0 && w > 1) weekly_own = -(w - 1);
+    }
     // the day's opening: roles (0 opens the day, 1 weekly imports, 2.. the test queue) by arrival ticket
     // (groups: the members share the chip, so each gets proportionally fewer workgroups per phase)
     int tg = grid_for(N / 64 + 1, PRO_THREADS, 64);
@@ -533,9 +550,10 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     uint32_t lds_crows = K > 1 ? e->group_lds_crows : e->h_tables.n_crows;
     if (lds_crows > REINA_LDS_CROWS) lds_crows = REINA_LDS_CROWS;
     {
-        const int g = 2 + tg;
+        const int helpers = weekly_own > 0 ? weekly_own : -weekly_own;
+        const int g0 = 1 + (helpers > 1 ? helpers : 1), g = g0 + tg;
         if (!e->testing_ever) {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(2, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0);
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g0, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0);
         } else if (ct && N <= 8000000u) {
             LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 3);  // detects + traces, both levels
         } else if (ct) {

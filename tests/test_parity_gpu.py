@@ -521,9 +521,14 @@ def test_three_variants():
     assert gpu.per_age_counters()['all_infected'].sum() > 3000
 
 
-def test_more_imports_in_a_day_than_one_chunk():
-    """40 000 + 9 000 infections imported on single days into 3 M agents (the import placement works in
-    chunks of 16 384), plus a big weekly flow -- bit-exact vs oracle B"""
+@pytest.mark.parametrize('import_wgs', [None, '1', '2'])
+def test_more_imports_in_a_day_than_one_chunk(import_wgs, monkeypatch):
+    """40 000 + 9 000 infections imported on single days into 3 M agents, plus a big weekly flow -- bit-exact vs oracle B.
+    A day's imports are shared by up to 16 workgroups (the opening one and its helpers, or the weekly imports' own), each
+    working in chunks of 16 384: by default one chunk over 16 workgroups; REINA_IMPORT_WGS=1: one workgroup, three chunks;
+    2: two workgroups, two chunks."""
+    if import_wgs is not None:
+        monkeypatch.setenv('REINA_IMPORT_WGS', import_wgs)
     v = copy.deepcopy(VARIABLE_DEFAULTS)
     v.update(hospital_beds=4000, icu_units=500)
     ivs = [['import-infections', '2020-02-19', 40000], ['import-infections', '2020-02-21', 9000, 'b1.1.7'],

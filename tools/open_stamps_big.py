@@ -17,3 +17,5 @@ for lo, hi in ((0, 118), (118, 200), (200, 365)):
     print('days %3d-%3d: opening until flag %.1f us/day, opening total %.1f, weekly-import workgroup %.1f | tracing workgroups: level0 loop mean %.1f (slowest ever %.1f, n=%d), wait %.1f, flush %.1f, level1 %.1f' % (
         lo, hi, us[5] / d, us[6] / d, us[9] / d, us[1] / max(1, m[25]), us[17], int(m[25]), us[2] / max(1, m[26]), us[3] / max(1, m[27]), us[4] / max(1, m[28])), flush=True)
     print('      slowest wave ever, us since the block started -- level 0: queue entry read %.1f, its record / slots / word in %.1f, flags set %.1f, overflow list walked %.1f | level 1: %.1f %.1f %.1f %.1f' % tuple(us[40:48]), flush=True)
+    print('      weekly-import workgroup, us/day: set-up %.1f propose %.1f any %.1f verify %.1f any %.1f (left the rounds %.1f) infect %.1f tail %.1f wait-open %.1f flush %.1f' % tuple(
+        us[48 + k] / d for k in (0, 1, 2, 3, 15, 4, 5, 6, 7, 8)), flush=True)
