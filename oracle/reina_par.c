@@ -983,7 +983,10 @@ static void run_remote(Par *e, const reina_day_t *dp) {
                                 uint64_t ent = tab[(r.v[3] + j) & (eff - 1)];
                                 if (ent < best) best = ent;   /* (smaller key = later day) */
                             }
-                            if (best != ~0ull && dp->day - (4095u - (uint32_t)(best >> 52)) <= RP_MIRROR_STALE_DAYS) {
+                            /* ... if it has not been removed since (k_remote.inc: the R statistics of an agent first seen
+                             * removed today must not depend on today's installs) */
+                            if (best != ~0ull && dp->day - (4095u - (uint32_t)(best >> 52)) <= RP_MIRROR_STALE_DAYS &&
+                                RH_STATE(e->buf.hot[(uint32_t)best]) < RS_RECOVERED) {
                                 src = (uint32_t)best;
                                 found = 1;
                             }
