@@ -25,7 +25,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/reina_hip.h"
@@ -150,6 +152,40 @@ static void free_engine(reina_engine *e) {
             return REINA_E_HIP;                                                              \
         }                                                                                    \
     } while (0)
+
+// One row of contact-count thresholds + its guide table (reina_contacts.h: 105 erfc + log in double, 4 us a row, 80 us for the
+// 20 distinct rows of a table -- host time that a short run cannot hide behind the GPU: the 20-day window of the round
+// driver's bench contains one table change, and it cost 5 us per step).  A row depends on one float only, and the same
+// values come back all the time -- a table change that closes schools leaves the other ages' rows as they were; every seed
+// of an ensemble, every scenario run of a serving process rebuilds the same tables on the same dates -- so rows are kept,
+// process-wide, keyed by the float's bits (at most 4096 rows, 1.5 MB; beyond that rows are computed and not kept).
+struct CountRow { uint32_t thr[REINA_COUNT_WORDS]; uint8_t guide[256]; };
+static void count_row_for(float nr_contacts, uint32_t *thr, uint8_t *guide) {
+    static std::mutex mu;
+    static std::unordered_map<uint32_t, CountRow> rows;
+    uint32_t key;
+    std::memcpy(&key, &nr_contacts, 4);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = rows.find(key);
+        if (it != rows.end()) {
+            std::memcpy(thr, it->second.thr, sizeof(it->second.thr));
+            std::memcpy(guide, it->second.guide, 256);
+            return;
+        }
+    }
+    CountRow row;
+    rc_count_thresholds(nr_contacts, row.thr);
+    int idx = 0;
+    for (uint32_t b = 0; b < 256; b++) {
+        while (idx < REINA_COUNT_FULL && row.thr[idx] <= (b << 24)) idx++;   // thresholds are non-decreasing
+        row.guide[b] = (uint8_t)idx;
+    }
+    std::memcpy(thr, row.thr, sizeof(row.thr));
+    std::memcpy(guide, row.guide, 256);
+    std::lock_guard<std::mutex> g(mu);
+    if (rows.size() < 4096) rows.emplace(key, row);
+}
 
 extern "C" {
 
@@ -429,12 +465,7 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
                 if (std::memcmp(&crow_value[r], &t->nr_contacts_by_age[a], sizeof(float)) == 0) break;
             if (r == n_crows) {
                 crow_value[r] = t->nr_contacts_by_age[a];
-                rc_count_thresholds(crow_value[r], T.cthr[r]);
-                int idx = 0;
-                for (uint32_t b = 0; b < 256; b++) {
-                    while (idx < REINA_COUNT_FULL && T.cthr[r][idx] <= (b << 24)) idx++;   // thresholds are non-decreasing
-                    T.cguide[r][b] = (uint8_t)idx;
-                }
+                count_row_for(crow_value[r], T.cthr[r], T.cguide[r]);
                 n_crows++;
             }
             T.crow_of_age[a] = (uint8_t)r;
@@ -476,17 +507,39 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
         }
     }
     std::memcpy(&e->stage[slot]->p, &e->h_params, sizeof(DevParams));
-    std::memcpy(&e->stage[slot]->t, &e->h_tables, sizeof(Tables));
+    UploadSegs segs;
+    {
+        const Tables &T = e->h_tables;
+        const uint32_t nr = T.n_rows ? T.n_rows : 1u, nc = T.n_crows ? T.n_crows : 1u;
+        const size_t seg[7][2] = {
+            {offsetof(Tables, thr), sizeof(T.thr[0]) * nr},
+            {offsetof(Tables, meta), sizeof(T.meta[0]) * nr},
+            {offsetof(Tables, guide), sizeof(T.guide[0]) * nr},
+            {offsetof(Tables, rcount), offsetof(Tables, cthr) - offsetof(Tables, rcount)},   // rcount, row_of_age, n_rows, uniform_meta
+            {offsetof(Tables, cthr), sizeof(T.cthr[0]) * nc},
+            {offsetof(Tables, cguide), sizeof(T.cguide[0]) * nc},
+            {offsetof(Tables, crow_of_age), sizeof(Tables) - offsetof(Tables, crow_of_age)},   // crow_of_age, n_crows, age_shift, age_block
+        };
+        segs.n = 7;
+        for (int q = 0; q < 7; q++) {
+            std::memcpy(reinterpret_cast<char *>(&e->stage[slot]->t) + seg[q][0], reinterpret_cast<const char *>(&T) + seg[q][0], seg[q][1]);
+            segs.off[q] = (uint32_t)(seg[q][0] / 4);
+            segs.words[q] = (uint32_t)(seg[q][1] / 4);
+        }
+        segs.off[7] = segs.words[7] = 0;
+    }
     // The transfer is a KERNEL that reads the pinned host slot directly (zero-copy): an ordinary
     // dispatch in the day stream.  hipMemcpyAsync of the 98 KB table was measured to block the host
     // for 7-8 ms once per run when >1000 dispatches were queued ahead of it (ROCm 7.2).
     void *dsrc = nullptr;
     HIP_CHECK(hipHostGetDevicePointer(&dsrc, e->stage[slot], 0));
-    static_assert(sizeof(DevParams) % 4 == 0 && sizeof(Tables) % 4 == 0 && offsetof(reina_engine::Stage, t) % 4 == 0, "word copies");
+    static_assert(sizeof(DevParams) % 4 == 0 && sizeof(Tables) % 4 == 0 && offsetof(reina_engine::Stage, t) % 4 == 0 &&
+                  offsetof(Tables, meta) % 4 == 0 && offsetof(Tables, guide) % 4 == 0 && offsetof(Tables, rcount) % 4 == 0 &&
+                  offsetof(Tables, cthr) % 4 == 0 && offsetof(Tables, cguide) % 4 == 0 && offsetof(Tables, crow_of_age) % 4 == 0, "word copies");
     const uint32_t *src_w = reinterpret_cast<const uint32_t *>(dsrc);
     hipLaunchKernelGGL(k_upload, dim3(64), dim3(256), 0, s, reinterpret_cast<uint32_t *>(e->d_params), src_w,
                        (uint32_t)(sizeof(DevParams) / 4), reinterpret_cast<uint32_t *>(e->d_tables),
-                       src_w + offsetof(reina_engine::Stage, t) / 4, (uint32_t)(sizeof(Tables) / 4));
+                       src_w + offsetof(reina_engine::Stage, t) / 4, segs);
     HIP_CHECK(hipEventRecord(e->stage_ev[slot], s));
     return REINA_OK;
 }
