@@ -20,4 +20,8 @@ for n in 1685983 50000000 100000000 200000000; do echo "== $n agents"; python to
 bash tools/gpu_ablate.sh > $OUT/ablation_1e8.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_scatter tools/ubench_scatter.hip 2>/dev/null && timeout 120 /tmp/ubench_scatter > $OUT/ubench_scatter.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/ubench_prims tools/ubench_prims.hip 2>/dev/null && timeout 120 /tmp/ubench_prims > $OUT/ubench_prims.txt
+# the bench line of this binary with `traffic` reported (profiles/traffic.json must carry its hash), and the round driver's window six times
+python bench.py > $OUT/final_bench.json 2> $OUT/final_bench.err
+for i in 1 2 3 4 5 6; do python bench.py --steps 20 --warmup 5 --no-cpu --no-sizes --no-ensemble 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print(b['ms_per_step'], b['value'], b['roofline']['kernel_us_per_day'])"; done > $OUT/driver_window_20_steps.txt
+python tools/run20_wall.py > $OUT/run20_wall.txt 2>/dev/null
 ls -la $OUT
