@@ -238,7 +238,7 @@ class Context:
         self._direct = getattr(comm, 'direct', None) if comm is not None else None
         self.shard_rank = comm.rank if comm is not None else 0
         self.n_shards = comm.world if comm is not None else 1
-        self._split = lambda x: split_count(x, self.shard_rank, self.n_shards)
+        self._split = (lambda x: x) if self.n_shards == 1 else (lambda x: split_count(x, self.shard_rank, self.n_shards))
         population_params = dict(population_params)
         ipc = population_params.pop('initial_population_condition', None)
 
@@ -467,21 +467,23 @@ class Context:
     def _build_day(self, history_ptr=None):
         """Host part of iterate(): interventions dated today, init_day bookkeeping -> reina_day_t.
         Returns (Day, tables_changed)."""
+        # (this function is host time per day, and a short run is host-bound -- DESIGN section 5: the interventions are indexed
+        # by day number, a population that is not sharded splits nothing, and without a weekly import flow its float32
+        # leftovers stay what they are: below 1, so no import either)
         if self._iv_index is None or self._iv_index[0] != len(self.interventions):
-            by_date = {}
-            for iv in self.interventions:  # list order is kept within a date (main.pyx:2013-2015)
-                by_date.setdefault(iv.date, []).append(iv)
-            self._iv_index = (len(self.interventions), by_date)
             self._date0 = date.fromisoformat(self.start_date)
+            by_day = {}
+            for iv in self.interventions:  # list order is kept within a date (main.pyx:2013-2015)
+                by_day.setdefault((date.fromisoformat(str(iv.date)) - self._date0).days, []).append(iv)
+            self._iv_index = (len(self.interventions), by_day)
         if self.day >= _eng.MAX_DAYS:
             raise SimulationFailed('Day counter overflow: the engine simulates at most %d days' % _eng.MAX_DAYS)
-        today = (self._date0 + timedelta(days=self.day)).isoformat()
-        for iv in self._iv_index[1].get(today, ()):
+        for iv in self._iv_index[1].get(self.day, ()):
             self.apply_intervention(iv)
         changed = self.contact_matrix.init_day()
         # Population.infect_people_daily (main.pyx:1671-1685): float32 leftover arithmetic
         weekly = []
-        for vid in range(self.nr_variants):
+        for vid in range(self.nr_variants if self.weekly_infections_amount else 0):
             leftover = np.float32(self.weekly_infections_leftover[vid])
             leftover = np.float32(float(leftover) + self.weekly_infections_amount / 7.0 * self.weekly_infections_shares[vid])
             amount_today = int(leftover)
