@@ -36,8 +36,8 @@ Objects on the line:
   ensemble       BASELINE config 5 per-GPU batch: 128 seeds of the HUS scenario as one engine group.
   cpu_baseline   the sequential C restatement of cythonsim (oracle/reina_seq.c, bit-exact vs the reference)
                  on one host core over THE SAME day window (W untimed, K timed days), repeated over seeds
-                 until about 10 s of timed work; `all_cores`: one simulation per core, first 120 days each
-                 (a different window: labelled).
+                 until about 10 s of timed work; `all_cores`: one simulation per core, all started together,
+                 over the same window (--cpu-all-cores-days n: the first n days instead, labelled).
 """
 import argparse
 import copy
@@ -261,6 +261,8 @@ from reina_model_amd import datasets
 from reina_model_amd.variables import VARIABLE_DEFAULTS
 ages = datasets.get_population_for_area()
 ctx = seq_oracle.make_context(copy.deepcopy(VARIABLE_DEFAULTS), ages, %(seed)d)
+for _ in range(%(warmup)d):          # the same untimed days as the GPU line
+    ctx.iterate()
 while time.time() < %(start)f:
     time.sleep(0.01)
 t0 = time.time()
@@ -272,14 +274,14 @@ print(t0, time.time())
 
 _CPU_HELPER = r"""
 import json, os, subprocess, sys, time
-root, days, procs, go = %(root)r, %(days)d, %(procs)d, %(go)r
+root, days, warmup, procs, go = %(root)r, %(days)d, %(warmup)d, %(procs)d, %(go)r
 worker = %(worker)r
 while not os.path.exists(go):          # the GPU measurements come first: all-core load slows the host
     time.sleep(0.05)
     if os.getppid() == 1:
         sys.exit(0)
-start = time.time() + 10.0
-ps = [subprocess.Popen([sys.executable, '-c', worker %% dict(root=root, seed=1000 + k, start=start, days=days)],
+start = time.time() + 10.0 + 0.05 * warmup
+ps = [subprocess.Popen([sys.executable, '-c', worker %% dict(root=root, seed=1000 + k, start=start, days=days, warmup=warmup)],
                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(procs)]
 spans = []
 for p in ps:
@@ -298,13 +300,15 @@ class CpuAllCores:
     after GPU initialisation); it starts its workers only when told to, after the GPU measurements,
     so that the all-core load cannot disturb them."""
 
-    def __init__(self, days, max_procs=64):
+    def __init__(self, days, max_procs=64, warmup=0):
         import tempfile
         self.days = days
+        self.warmup = warmup
+        self.same_window = False
         self.procs = min(os.cpu_count() or 1, max_procs)
         self.max_procs = max_procs
         self.go = os.path.join(tempfile.gettempdir(), 'reina_bench_go_%d' % os.getpid())
-        code = _CPU_HELPER % dict(root=ROOT, days=days, procs=self.procs, go=self.go, worker=_CPU_WORKER)
+        code = _CPU_HELPER % dict(root=ROOT, days=days, warmup=warmup, procs=self.procs, go=self.go, worker=_CPU_WORKER)
         self.helper = subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
 
     def run(self):
@@ -324,8 +328,9 @@ class CpuAllCores:
         wall = max(b for _, b in spans) - min(a for a, _ in spans)
         return dict(value=round(HUS_AGENTS * self.days * len(spans) / wall, 1), unit='agent-days/s', cores=len(spans), kind='port',
                     sample='%d concurrent sequential simulations (one per core, cores capped at %d), HUS %d agents, '
-                           'FIRST %d DAYS each (not the GPU line\'s window), %.1f s wall' % (
-                               len(spans), self.max_procs, HUS_AGENTS, self.days, wall))
+                           '%d untimed + %d timed days each%s, %.1f s wall' % (
+                               len(spans), self.max_procs, HUS_AGENTS, self.warmup, self.days,
+                               ' (the GPU line\'s window)' if self.same_window else ' (NOT the GPU line\'s window)', wall))
 
 
 def ensemble_line(seeds, days, device, dist=None):
@@ -398,7 +403,9 @@ def main():
     ap.add_argument('--no-large', action='store_true')
     ap.add_argument('--no-ensemble', action='store_true')
     ap.add_argument('--ensemble-seeds', type=int, default=128)
-    ap.add_argument('--cpu-all-cores-days', type=int, default=120)
+    ap.add_argument('--cpu-all-cores-days', type=int, default=-1,
+                    help='all-cores CPU baseline: -1 = the window of the GPU line (--warmup untimed + --steps timed days), '
+                         '0 = off, n > 0 = the first n days')
     ap.add_argument('--cpu-max-procs', type=int, default=64, help='concurrent CPU simulations of the all-cores baseline')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--time-every', type=int, default=0,
@@ -413,8 +420,13 @@ def main():
     stride = stride_for(a.steps, a.time_every)
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
     cpu_all = None
-    if world_env == 1 and not a.no_cpu and not a.agents and a.cpu_all_cores_days > 0:
-        cpu_all = CpuAllCores(a.cpu_all_cores_days, a.cpu_max_procs)   # helper spawned before anything initialises the GPU; runs last
+    if world_env == 1 and not a.no_cpu and not a.agents and a.cpu_all_cores_days != 0:
+        # helper spawned before anything initialises the GPU; runs last
+        if a.cpu_all_cores_days < 0:
+            cpu_all = CpuAllCores(a.steps, a.cpu_max_procs, warmup=a.warmup)
+            cpu_all.same_window = True
+        else:
+            cpu_all = CpuAllCores(a.cpu_all_cores_days, a.cpu_max_procs)
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
