@@ -168,41 +168,36 @@ RP_HD float rp_logf(float x) {
 }
 
 // ------------------------------------------------------------------ standard normal from one u32
-// Inverse-CDF (P. J. Acklam's rational approximation; |rel err| ~ 1e-9 in exact arithmetic,
-// ~1e-6 here). u is the centre of one of 2^32 equal cells of (0,1): never 0 or 1.
+// Inverse CDF by M. J. Wichura's algorithm AS 241, routine PPND7 (Appl. Statist. 37, 1988: "about seven decimal digits"),
+// the single-precision member of the pair -- rational functions with small positive coefficients that evaluate well in float.
+// u is the centre of one of 2^32 equal cells of (0,1): never 0 or 1; a tail is computed on the exact cell of its own side, so
+// the two tails mirror each other bit for bit.  (Rounds 1-2 used P. J. Acklam's approximation, whose large alternating
+// coefficients needed double arithmetic: 650 SIMD cycles per wave call against 270 -- the draw sits inside the gamma draws of
+// every infection and every symptom onset, a quarter of the day's last launch at an epidemic peak.)
 RP_HD float rp_normal_from_u32(uint32_t r) {
     // p = (r + 0.5) / 2^32 computed in two exact steps: hi 24 bits + low 8 bits
-    float p = ((float)(r >> 8) + ((float)(r & 0xFFu) + 0.5f) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);
-    // the rational polynomials have large alternating coefficients: evaluate them in double
-    // (IEEE basic ops, identical on host and device); log/sqrt of the tails stay in float
-    const double a0 = -3.969683028665376e+01, a1 = 2.209460984245205e+02, a2 = -2.759285104469687e+02,
-                 a3 = 1.383577518672690e+02, a4 = -3.066479806614716e+01, a5 = 2.506628277459239e+00;
-    const double b0 = -5.447609879822406e+01, b1 = 1.615858368580409e+02, b2 = -1.556989798598866e+02,
-                 b3 = 6.680131188771972e+01, b4 = -1.328068155288572e+01;
-    const double c0 = -7.784894002430293e-03, c1 = -3.223964580411365e-01, c2 = -2.400758277161838e+00,
-                 c3 = -2.549732539343734e+00, c4 = 4.374664141464968e+00, c5 = 2.938163982698783e+00;
-    const double d0 = 7.784695709041462e-03, d1 = 3.224671290700398e-01, d2 = 2.445134137142996e+00,
-                 d3 = 3.754408661907416e+00;
-    const float plow = 0.02425f;
-    float x;
-    if (p < plow) {
-        double q = (double)sqrtf(-2.0f * rp_logf(p));
-        x = (float)((((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) /
-                    ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0));
-    } else if (p <= 1.0f - plow) {
-        double q = (double)p - 0.5;
-        double t = q * q;
-        x = (float)((((((a0 * t + a1) * t + a2) * t + a3) * t + a4) * t + a5) * q /
-                    (((((b0 * t + b1) * t + b2) * t + b3) * t + b4) * t + 1.0));
-    } else {
-        // upper tail by symmetry on the exact complement cell: 1-p = ((2^32-1-r) + 0.5)/2^32
-        uint32_t rc = 0xFFFFFFFFu - r;
-        float pc = ((float)(rc >> 8) + ((float)(rc & 0xFFu) + 0.5f) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);
-        double q = (double)sqrtf(-2.0f * rp_logf(pc));
-        x = (float)(-(((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) /
-                    ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0));
+    const float p = ((float)(r >> 8) + ((float)(r & 0xFFu) + 0.5f) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);
+    const float q = p - 0.5f;
+    if (q >= -0.425f && q <= 0.425f) {
+        const float t = 0.180625f - q * q;
+        return q * (((5.9109374720e+01f * t + 1.5929113202e+02f) * t + 5.0434271938e+01f) * t + 3.3871327179e+00f) /
+               (((6.7187563600e+01f * t + 7.8757757664e+01f) * t + 1.7895169469e+01f) * t + 1.0f);
     }
-    return x;
+    const int upper = q > 0.0f;
+    const uint32_t rc = upper ? 0xFFFFFFFFu - r : r;   // the cell counted from the nearer end
+    const float pc = ((float)(rc >> 8) + ((float)(rc & 0xFFu) + 0.5f) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);
+    float s = sqrtf(-rp_logf(pc));
+    float x;
+    if (s <= 5.0f) {
+        s = s - 1.6f;
+        x = (((1.7023821103e-01f * s + 1.3067284816e+00f) * s + 2.7568153900e+00f) * s + 1.4234372777e+00f) /
+            ((1.2021132975e-01f * s + 7.3700164250e-01f) * s + 1.0f);
+    } else {
+        s = s - 5.0f;
+        x = (((1.7337203997e-02f * s + 4.2868294337e-01f) * s + 3.0812263860e+00f) * s + 6.6579051150e+00f) /
+            ((1.2258202635e-02f * s + 2.4197894225e-01f) * s + 1.0f);
+    }
+    return upper ? x : -x;
 }
 
 // ------------------------------------------------------------------ gamma (Marsaglia-Tsang, shape >= 1)

@@ -109,8 +109,9 @@ def test_kernels_fit_the_lds_they_ask_for():
     assert all(d['.vgpr_count:'] == 128 for d in day), day
     for k, v in kernels.items():
         # the streaming kernel must not touch scratch; the day's last launch (event walk + installs in one kernel) may
-        # park a handful of registers
-        assert v.get('.vgpr_spill_count:', 0) <= (8 if 'k_hosp_install' in k else 0), (k, v)
+        # park a handful of registers in its engine-group instantiation, none in the single-engine one
+        limit = 16 if 'k_hosp_installILb1' in k else 0
+        assert v.get('.vgpr_spill_count:', 0) <= limit, (k, v)
 
 
 def test_k_day_keeps_its_hand_reserved_registers_to_itself():
