@@ -107,6 +107,28 @@ def test_day_descriptors_follow_the_schedule():
     assert abs(d2.p_successful_tracing - 0.3) < 1e-7
 
 
+def test_interventions_are_found_by_day_number_whatever_carries_their_date():
+    """the schedule is indexed by day number (not by comparing date strings every day): an ISO string and a datetime.date land
+    on the same day, list order within a date is kept, a date before the start never applies, a malformed date is an error"""
+    from datetime import date
+    from reina_model_amd.interventions import Intervention
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ctx = simulation.make_context(v, age_counts=datasets.scaled_population(5000), seed=1, interventions=[],
+                                  engine_factory=par_backend.par_engine_factory)
+    ctx.add_intervention(Intervention('build-new-hospital-beds', date(2020, 2, 20), {'beds': 5}))
+    ctx.add_intervention(Intervention('build-new-hospital-beds', '2020-02-20', {'beds': 7}))
+    ctx.add_intervention(Intervention('build-new-hospital-beds', '2020-01-01', {'beds': 1000}))   # before the start date
+    adds = []
+    for _ in range(4):
+        d, _ = ctx._build_day()
+        ctx.day += 1
+        adds.append(d.add_beds)
+    assert adds == [0, 0, 12, 0]
+    ctx.add_intervention(Intervention('build-new-hospital-beds', '20/02/2020', {'beds': 1}))
+    with pytest.raises(ValueError):
+        ctx._build_day()
+
+
 def test_unknown_intervention_type_raises_like_the_reference():
     v = copy.deepcopy(VARIABLE_DEFAULTS)
     ctx = simulation.make_context(v, age_counts=datasets.scaled_population(3000), seed=1, interventions=[],
