@@ -959,7 +959,9 @@ static void run_remote(Par *e, const reina_day_t *dp) {
                             const uint64_t *tab = e->buf.mirror + (size_t)cell * S;
                             for (uint32_t j = 0; j < probes; j++) {
                                 uint64_t ent = tab[(r.v[3] + j) & (eff - 1)];
-                                if ((ent >> 52) == ((4095u - dp->day) & 0xFFFu)) {
+                                /* (not removed by today's scan: k_remote.inc) */
+                                if ((ent >> 52) == ((4095u - dp->day) & 0xFFFu) &&
+                                    (((uint32_t)ent & RP_REMOTE_SRC) || RH_STATE(e->buf.hot[(uint32_t)ent]) < RS_RECOVERED)) {
                                     src = (uint32_t)ent;
                                     found = 1;
                                     break;

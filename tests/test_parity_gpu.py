@@ -227,14 +227,17 @@ def test_sharded_population_two_shards_on_one_gpu():
     assert tot[eng.C_NAMES.index('all_infected') * eng.MAX_AGES:][:101].sum() > 5000
 
 
-@pytest.mark.parametrize('case', [155, 489, 703, 822, 1008, 2034, 2058, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize('case', [155, 489, 703, 822, 1008, 2034, 2058, 200812, 7, 8, 9, 10, 11])
 def test_random_scenarios_on_two_to_four_shards(case):
     """The sharded leg of the randomised soak (tools/parity_soak.py ... sharded) in the suite: random scenarios on 2-4
     in-process shards, HIP == oracle B on every tenth day's counters and on the final state.  The first seven are scenarios
     on which the soak of round 3 found mismatches that did not repeat run to run -- a stale stand-in infector (mirror
     attribution, a small outbreak) that had been removed since: the R statistics of an agent first seen removed today are read
     by the launch that would add today's infection to its count.  A stand-in must not be a removed agent (k_remote.inc,
-    oracle run_remote); 3200 further sharded scenarios then ran clean."""
+    oracle run_remote); 3200 further sharded scenarios then ran clean.  Case 200812 is the scenario on which a later soak found a
+    HOLE in a source's inline infectee slots: a stand-in of TODAY that today's scan had removed (its list given up) took an
+    infection count without a slot while a contact of the same morning took the next count with one -- a stand-in of any age
+    must be an agent that has not been removed."""
     import par_backend
     from reina_model_amd import sharding
     rng = np.random.default_rng(300000 + case)
