@@ -113,6 +113,9 @@ enum {
     REINA_L_SORT_TICKET,                                /* the same for a sharded population's pre-sort of its event buckets */
     REINA_L_IMPORT_SYNC,                                /* [4] arrival words of the workgroups that share a day's weekly imports (zeroed by the
                                                            day's last launch) */
+    REINA_L_ACTIVE = 24,                                /* [2] agents the daily stream found something to do for (infected, or removed and not
+                                                           yet counted into R), word [day & 1]: yesterday's count tells k_day whether to stream
+                                                           every hot word or only buffers.active_bits (sparse days) */
     REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_DET_SIDE = 48,                              /* [REINA_MAX_AGES] the day's detections by age from the test queue (the day's opening
                                                            launch), folded into the counters by the day's last launch */
@@ -278,7 +281,18 @@ typedef struct {
     uint32_t *scan_lists;     /* [4 * max_work_items] two lists of (agent, kind) pairs written by the
                                  scan: hospital events, then bookkeeping (R statistics, home
                                  recoveries / deaths). The other two lists live in work_items. */
+    uint32_t *active_bits;    /* [REINA_BITS_WORDS(n_agents)] one bit per agent (bit i & 31 of word i >> 5): the hot word's ACTIVE
+                                 flag again -- "the daily stream has something to do for this agent" (infected, or removed and
+                                 not yet counted into R).  On a day with few such agents k_day streams these 1/32 of the hot
+                                 words' bytes and fetches only the words of the agents whose bit is set (Context._iterate_people
+                                 skips everybody else at once too: `if not person.is_infected: return`, main.pyx:1974-1975) */
+    uint32_t *infected_bits;  /* [REINA_BITS_WORDS(n_agents)] one bit per agent: has ever been infected, i.e. is not SUSCEPTIBLE
+                                 (person_expose's test, main.pyx:239).  A contact that can transmit looks its target up here --
+                                 a table of N / 8 bytes that stays in the 256 MB Infinity Cache -- instead of gathering the
+                                 target's hot word from HBM */
 } reina_buffers_t;
+/* words of a per-agent bit plane: whole 512-agent tiles of 16 words (k_day's wave tiles), and one spare tile */
+#define REINA_BITS_WORDS(n_agents) ((((size_t)(n_agents) + 511u) / 512u + 1u) * 16u)
 
 /* `pre_init` = 1 for batches that come from an `import-infections` intervention: the reference
  * applies those BEFORE Population.init_day zeroes new_infections / infected_by_variant

@@ -68,7 +68,7 @@ static int age_of(const Par *e, uint32_t i) {
     return lo;
 }
 
-int par_abi_version(void) { return 3; }
+int par_abi_version(void) { return 4; }
 
 /* Context.sample: the shared host-side sampler (utility, not part of the day step) */
 int par_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,

@@ -189,7 +189,7 @@ static void count_row_for(float nr_contacts, uint32_t *thr, uint8_t *guide) {
 
 extern "C" {
 
-int reina_abi_version(void) { return 3; }
+int reina_abi_version(void) { return 4; }
 
 #ifdef REINA_ABLATE
 int reina_debug_ablate(uint32_t bits) {   // diagnostic builds only (tools/ablate_day.py)
@@ -268,6 +268,19 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
             const int v = std::atoi(w);
             if (v >= 1 && v <= 16) e->import_wgs = (uint32_t)v;
         }
+        // k_day streams the bit plane instead of the hot words when yesterday's stream found fewer than n_agents / div active
+        // agents (k_contacts.inc).  REINA_DAY_MODE = dense | sparse forces one form (the tests run every scenario in both),
+        // REINA_DAY_SPARSE_DIV moves the threshold, REINA_DAY_FLAGS are k_day's measurement switches (DAY_F_*)
+        e->day_sparse_below = cfg->n_agents / REINA_DAY_SPARSE_DIV_DEFAULT;
+        if (const char *w = std::getenv("REINA_DAY_SPARSE_DIV")) {
+            const int v = std::atoi(w);
+            if (v >= 1) e->day_sparse_below = cfg->n_agents / (uint32_t)v;
+        }
+        if (const char *w = std::getenv("REINA_DAY_MODE")) {
+            if (!std::strcmp(w, "dense")) e->day_sparse_below = 0u;
+            else if (!std::strcmp(w, "sparse")) e->day_sparse_below = 0xFFFFFFFFu;
+        }
+        if (const char *w = std::getenv("REINA_DAY_FLAGS")) e->day_flags = (uint32_t)std::atoi(w);
     }
     std::memset(&e->h_params, 0, sizeof(DevParams));
     std::memset(&e->h_tables, 0, sizeof(Tables));
@@ -618,7 +631,8 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         // a vaccination programme: its pass over the agents comes after the test queue and before the stream
         // (HealthcareSystem.iterate, main.pyx:514-558)
         if (dp.n_vaccinations) LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, dp);
-        LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows);
+        LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows,
+                   e->day_sparse_below, e->day_flags);
     }
     e->cur_scan_waves = day_blocks * DAY_WAVES;   // (the day's later launches walk the per-wave slices)
     if (e->cfg.n_shards > 1) {

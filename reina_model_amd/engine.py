@@ -45,7 +45,7 @@ COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 48 + MAX_AGES   # REINA_L_NR (48 named words and cursors + the detections-by-age side block)
 L_HOSP_PEAK = 12   # control word: bed / ICU event count of the busiest day on which the events' order mattered
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
-ABI_VERSION = 3   # reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays)
+ABI_VERSION = 4   # reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays; round 4: the two per-agent bit planes)
 INLINE_INFECTEES = 8   # REINA_INLINE_INFECTEES
 COLD_WORDS = 8         # sizeof(reina_cold_t) / 4: claim (2 words), infector, n_infected, onset_days, vacc_day, first_infectee, next_sibling
 COLD_FIELDS = dict(infector=2, n_infected=3, onset_days=4, vacc_day=5, first_infectee=6, next_sibling=7)   # word of each 32-bit field
@@ -99,7 +99,8 @@ class ContactTablesABI(ctypes.Structure):
 
 
 BUFFER_FIELDS = ('hot', 'cold', 'infectees', 'counters', 'control', 'work_items', 'candidates',
-                 'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'mirror_meta', 'work_counts', 'scan_lists')
+                 'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'mirror_meta', 'work_counts', 'scan_lists',
+                 'active_bits', 'infected_bits')
 
 
 class Buffers(ctypes.Structure):
@@ -162,6 +163,11 @@ def hosp_event_words(n_agents, max_hosp_events, ranges=0):
     """include/reina_hip.h: REINA_HOSP_EVENT_WORDS(_R) (64-bit words of buffers.hosp_events)"""
     r = ranges or hosp_ranges(n_agents)
     return r // 2 + 2 * r + r * hosp_bucket_cap(n_agents, max_hosp_events, r)
+
+
+def bits_words(n_agents):
+    """include/reina_hip.h: REINA_BITS_WORDS -- uint32 words of a per-agent bit plane (buffers.active_bits / infected_bits)"""
+    return ((n_agents + 511) // 512 + 1) * 16
 
 
 def exchange_words(n_shards, ranges):
@@ -336,6 +342,9 @@ class Engine:
             mirror_meta=a.zeros(2 * MAX_RANGES * MAX_VARIANTS, np.uint32),
             work_counts=a.zeros(5 * MAX_SCAN_WAVES, np.uint32),
             scan_lists=a.zeros(4 * config.max_work_items, np.uint32),
+            # one bit per agent each: the hot word's ACTIVE flag again (what k_day streams on a sparse day) / ever infected
+            # (what a contact looks its target up in)
+            active_bits=a.zeros(bits_words(n), np.uint32), infected_bits=a.zeros(bits_words(n), np.uint32),
         )
         bufs = Buffers(**{k: a.ptr(v) for k, v in self.tensors.items()})
         self._check(self.f['bind_buffers'](self._h, ctypes.byref(bufs)), 'bind_buffers')

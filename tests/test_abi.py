@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), name
     f = eng.bind_abi(lib, 'reina_')
-    assert f["abi_version"]() == eng.ABI_VERSION == 3
+    assert f["abi_version"]() == eng.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_the_header_sizes():
@@ -110,7 +110,7 @@ def test_kernels_fit_the_lds_they_ask_for():
     for k, v in kernels.items():
         # the streaming kernel must not touch scratch; the day's last launch (event walk + installs in one kernel) may
         # park a handful of registers in its engine-group instantiation, none in the single-engine one
-        limit = 16 if 'k_hosp_installILb1' in k else 0
+        limit = 24 if 'k_hosp_installILb1' in k else 0
         assert v.get('.vgpr_spill_count:', 0) <= limit, (k, v)
 
 
@@ -144,7 +144,7 @@ def test_k_day_keeps_its_hand_reserved_registers_to_itself():
             body.append(line.split('//')[0].strip())
     assert len(body) > 1000
     high = re.compile(r'\bv(?:\[)?(1(?:0[4-9]|1[0-9]|2[0-7]))\b')   # v104..v127, alone or as the start of a range
-    loads = reads = 0
+    loads = reads = moves = 0
     for ins in body:
         op = ins.split()[0]
         assert not op.startswith(('s_swappc', 's_call', 's_setpc')), 'k_day calls out: %s' % ins
@@ -160,11 +160,14 @@ def test_k_day_keeps_its_hand_reserved_registers_to_itself():
             assert dst and 104 <= int(dst.group(1)) and int(dst.group(2)) <= 127, ins
             loads += 1
         else:
-            assert op == 'v_bfe_u32', 'a compiler-scheduled instruction touches the reserved tile registers: %s' % ins
+            # readers: the dense day's v_bfe_u32 (ACTIVE bit of a hot word) and the sparse day's v_mov_b32 (a set of bit words
+            # taken into compiler-visible registers), both written in the asm blocks
+            assert op in ('v_bfe_u32', 'v_mov_b32_e32'), 'a compiler-scheduled instruction touches the reserved tile registers: %s' % ins
             ops = [x.strip(' ,') for x in ins.split()[1:]]
-            assert not re.match(r'v\[?1(0[4-9]|1\d|2[0-7])', ops[0]), 'v_bfe_u32 writes a reserved register: %s' % ins
+            assert not re.match(r'v\[?1(0[4-9]|1\d|2[0-7])', ops[0]), '%s writes a reserved register: %s' % (op, ins)
             reads += 1
-    assert loads >= 6 and reads >= 24, (loads, reads)
+            moves += op == 'v_mov_b32_e32'
+    assert loads >= 12 and reads >= 24 + 24 and moves >= 24, (loads, reads, moves)
     # kernel descriptor: no scratch at all
     name, fields = None, {}
     for line in notes.splitlines():

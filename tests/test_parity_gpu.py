@@ -24,8 +24,24 @@ def _pair(variables, ages, seed, interventions=None, ipc=None):
     return gpu, cpu
 
 
+def _assert_bit_planes(gpu):
+    """the two per-agent bit planes of the HIP engine (include/reina_hip.h: active_bits, infected_bits) say what the hot
+    words say: bit i of active_bits == the ACTIVE flag of hot[i] (what a sparse day's stream reads instead of the words),
+    bit i of infected_bits == hot[i] is not SUSCEPTIBLE (what a contact looks its target up in); no bit beyond the agents"""
+    t = gpu.engine.tensors
+    hot = gpu.engine.alloc.to_host(t['hot']).view(np.uint32)
+    n = len(hot)
+    for name, want in (('active_bits', (hot & 0x8000) != 0), ('infected_bits', (hot & 7) != 0)):
+        words = np.ascontiguousarray(gpu.engine.alloc.to_host(t[name]).view(np.uint32))
+        bits = np.unpackbits(words.view(np.uint8), bitorder='little').astype(bool)
+        assert np.array_equal(bits[:n], want), name
+        assert not bits[n:].any(), name + ': bits beyond the last agent'
+
+
 def _assert_state_equal(gpu, cpu):
     tg, tc = gpu.engine.tensors, cpu.engine.tensors
+    if isinstance(gpu.engine.alloc, eng.TorchAllocator):   # (the HIP engine; the CPU checker keeps no bit planes)
+        _assert_bit_planes(gpu)
     for name in ('hot', 'infector', 'n_infected', 'vacc_day'):
         a = gpu.engine.alloc.to_host(tg[name]).view(np.uint32)
         b = np.asarray(tc[name]).view(np.uint32)
@@ -139,6 +155,58 @@ def test_mini_imports_only():
     _, meta = load_run('mini_imports_s1')
     _run_and_compare(variables_for(meta), np.asarray(meta['age_counts']), meta['seed'], meta['days'],
                      interventions=meta['interventions'])
+
+
+@pytest.mark.parametrize('mode', ['dense', 'sparse'])
+def test_sparse_and_dense_days_are_the_same_day(mode, monkeypatch):
+    """k_day streams either every hot word (dense day) or the ACTIVE bit plane and the words of the agents it names
+    (sparse day, round 4) -- chosen per day from yesterday's count of active agents.  Forced one way and the other
+    (REINA_DAY_MODE), every scenario family gives oracle B's results bit for bit: the mini default scenario through its
+    peak (a third of the population infected -- in the sparse form every lane then queues several agents per step), all
+    intervention types, population sizes that are not a multiple of 4 / of a tile, random scenarios with initial
+    conditions, three variants with tracing."""
+    monkeypatch.setenv('REINA_DAY_MODE', mode)
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=12, icu_units=2)
+    _run_and_compare(v, datasets.scaled_population(20000), 4, 200)
+    _, meta = load_run('mini_kitchen_s0')
+    _run_and_compare(variables_for(meta), np.asarray(meta['age_counts']), meta['seed'], meta['days'],
+                     interventions=meta['interventions'])
+    v.update(hospital_beds=3, icu_units=1)
+    for total in (4099, 10007, 511, 513, 2049):
+        _run_and_compare(v, datasets.scaled_population(total), 11, 90)
+    for case in (3, 8, 14):
+        rng = np.random.default_rng(1000 + case)
+        vv, ages, days, ivs, ipc = _random_scenario(rng)
+        _run_and_compare(vv, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
+
+
+def test_sparse_dense_and_mixed_years_of_the_hus_population_are_identical(monkeypatch):
+    """BASELINE configs[1] (1 685 983 agents x 365 days): the year as run by default (sparse days below 2.5 % active agents,
+    dense days above: both forms occur), all days dense and all days sparse give the identical history and final state;
+    the default one is compared with oracle B in test_hus_full_population_full_year."""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ages = datasets.get_population_for_area()
+    runs = {}
+    for mode in ('auto', 'dense', 'sparse'):
+        if mode == 'auto':
+            monkeypatch.delenv('REINA_DAY_MODE', raising=False)
+        else:
+            monkeypatch.setenv('REINA_DAY_MODE', mode)
+        ctx = simulation.make_context(v, age_counts=ages, seed=2)
+        hist = ctx.run(365)
+        _assert_bit_planes(ctx)
+        t = ctx.engine.tensors
+        runs[mode] = (hist, [ctx.engine.alloc.to_host(t[k]).copy() for k in ('hot', 'infector', 'n_infected', 'onset_days')])
+        del ctx
+    for mode in ('dense', 'sparse'):
+        assert np.array_equal(runs['auto'][0], runs[mode][0]), mode
+        for a, b in zip(runs['auto'][1], runs[mode][1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
+    # (and the default year did use both forms: its active count crosses the threshold)
+    A = eng.MAX_AGES
+    infected = runs['auto'][0][:, 0:A].sum(axis=1)
+    assert infected.min() < int(ages.sum()) // 100 and infected.max() > int(ages.sum()) // 20
 
 
 def test_eager_iterate_equals_batched_run():
