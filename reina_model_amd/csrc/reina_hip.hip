@@ -278,9 +278,9 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         }
         if (const char *w = std::getenv("REINA_DAY_MODE")) {
             if (!std::strcmp(w, "dense")) e->day_sparse_below = 0u;
-            else if (!std::strcmp(w, "sparse")) e->day_sparse_below = 0xFFFFFFFFu;
+            else if (!std::strcmp(w, "sparse")) { e->day_sparse_below = 0xFFFFFFFFu; e->day_flags |= DAY_F_SPARSE_ANY; }
         }
-        if (const char *w = std::getenv("REINA_DAY_FLAGS")) e->day_flags = (uint32_t)std::atoi(w);
+        if (const char *w = std::getenv("REINA_DAY_FLAGS")) e->day_flags |= (uint32_t)std::atoi(w);
     }
     std::memset(&e->h_params, 0, sizeof(DevParams));
     std::memset(&e->h_tables, 0, sizeof(Tables));

@@ -155,7 +155,10 @@ def test_k_day_keeps_its_hand_reserved_registers_to_itself():
             for a, b in re.findall(r'v\[(\d+):(\d+)\]', ins):
                 assert int(b) < 104, ins
             continue
-        if op == 'global_load_dwordx4':
+        if op == 'global_load_dword':   # (a sparse day's fetch of the queued agents' hot words)
+            assert re.match(r'global_load_dword\s+v124,', ins), ins
+            loads += 1
+        elif op == 'global_load_dwordx4':
             dst = re.match(r'global_load_dwordx4\s+v\[(\d+):(\d+)\]', ins)
             assert dst and 104 <= int(dst.group(1)) and int(dst.group(2)) <= 127, ins
             loads += 1
