@@ -149,6 +149,9 @@ def test_k_day_keeps_its_hand_reserved_registers_to_itself():
         op = ins.split()[0]
         assert not op.startswith(('s_swappc', 's_call', 's_setpc')), 'k_day calls out: %s' % ins
         assert not op.startswith('scratch_'), 'k_day touches scratch: %s' % ins
+        # (a flat_* access counts against vmcnt AND lgkmcnt and may retire out of order with the global loads: the counted
+        # wait in front of a tile's registers, s_waitcnt vmcnt(4), would no longer mean that the tile has landed)
+        assert not op.startswith('flat_'), 'k_day uses a generic-address access: %s' % ins
         regs = [int(x) for x in re.findall(r'\bv\[?(\d+)', ins)]
         if not any(r >= 104 for r in regs):
             # (a range that starts below 104 must not reach into the reserved set either)
