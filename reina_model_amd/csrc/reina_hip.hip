@@ -281,6 +281,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
             else if (!std::strcmp(w, "sparse")) { e->day_sparse_below = 0xFFFFFFFFu; e->day_flags |= DAY_F_SPARSE_ANY; }
         }
         if (const char *w = std::getenv("REINA_DAY_FLAGS")) e->day_flags |= (uint32_t)std::atoi(w);
+        if (const char *w = std::getenv("REINA_IMPORTS_IN_OPEN")) e->imports_in_open = std::atoi(w) != 0;   // (the round-3 placement, for comparison)
     }
     std::memset(&e->h_params, 0, sizeof(DevParams));
     std::memset(&e->h_tables, 0, sizeof(Tables));
@@ -610,13 +611,22 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     if (K > 1 && tg > (int)(e->n_cus / K)) tg = e->n_cus / K > 0 ? (int)(e->n_cus / K) : 1;
     const bool ct = dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
     const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
-    const uint32_t day_blocks = day_blocks_for(N, K, e->n_cus);
+    uint32_t day_blocks = day_blocks_for(N, K, e->n_cus);
+    // weekly imports on a day without intervention imports are placed in k_day's launch, beside the stream, by workgroups
+    // of their own behind the streaming ones (k_open.inc: deferred placement); all of them fit the chip together
+    uint32_t stream_imports = 0;
+    if (weekly_own > 0 && dp.day + 1u < REINA_MAX_DAYS && !e->imports_in_open) {
+        stream_imports = K == 1 ? (uint32_t)weekly_own : 1u;
+        const uint32_t cap = K > 1 ? (e->n_cus / K > 0 ? e->n_cus / K : 1u) : e->n_cus;
+        if (day_blocks + stream_imports > cap && cap > stream_imports) day_blocks = cap - stream_imports;
+        weekly_own = OPEN_WEEKLY_IN_STREAM;
+    }
     uint32_t lds_rows = K > 1 ? e->group_lds_rows : e->h_tables.n_rows;   // (a member stages min(its own rows, lds_rows))
     if (lds_rows > REINA_LDS_ROWS) lds_rows = REINA_LDS_ROWS;
     uint32_t lds_crows = K > 1 ? e->group_lds_crows : e->h_tables.n_crows;
     if (lds_crows > REINA_LDS_CROWS) lds_crows = REINA_LDS_CROWS;
     {
-        const int helpers = weekly_own > 0 ? weekly_own : -weekly_own;
+        const int helpers = weekly_own == OPEN_WEEKLY_IN_STREAM ? 0 : weekly_own > 0 ? weekly_own : -weekly_own;
         const int g0 = 1 + (helpers > 1 ? helpers : 1), g = g0 + tg;
         if (!e->testing_ever) {
             LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g0, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0);
@@ -631,8 +641,8 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         // a vaccination programme: its pass over the agents comes after the test queue and before the stream
         // (HealthcareSystem.iterate, main.pyx:514-558)
         if (dp.n_vaccinations) LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, dp);
-        LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows,
-                   e->day_sparse_below, e->day_flags);
+        LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks + stream_imports, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows,
+                   e->day_sparse_below, e->day_flags, stream_imports);
     }
     e->cur_scan_waves = day_blocks * DAY_WAVES;   // (the day's later launches walk the per-wave slices)
     if (e->cfg.n_shards > 1) {

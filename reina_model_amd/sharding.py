@@ -5,8 +5,10 @@ are local; the only per-day coupling is that a contact is a uniform member of an
 WHOLE population.  Each shard therefore counts, per (destination shard, contact age range,
 variant), the transmissible contacts it aims at other shards; one small all-reduce (2048 int32
 over RCCL/xGMI, latency-bound) sums these "infection pressure" histograms, and each shard realises
-the pressure aimed at it on uniformly drawn local agents.  Global scarce resources (beds, ICU
-units, import and vaccination quotas) are partitioned 1/G per shard.
+the pressure aimed at it on uniformly drawn local agents.  Beds and ICU units are ONE pool over the
+shards, handed out in one global order (priority bucket, shard, priority, agent) from per-bucket event
+maps that ride on the same all-reduce (csrc/k_remote.inc); import and vaccination
+quotas are partitioned 1/G per shard.
 
 Infector links across shards ("mirror attribution"): the true infector of a cross-shard infection
 lives on another shard and is never shipped.  Shards are statistically exchangeable, so an
