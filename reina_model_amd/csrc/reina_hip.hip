@@ -271,7 +271,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         // k_day streams the bit plane instead of the hot words when yesterday's stream found fewer than n_agents / div active
         // agents (k_contacts.inc).  REINA_DAY_MODE = dense | sparse forces one form (the tests run every scenario in both),
         // REINA_DAY_SPARSE_DIV moves the threshold, REINA_DAY_FLAGS are k_day's measurement switches (DAY_F_*)
-        e->day_sparse_below = cfg->n_agents / REINA_DAY_SPARSE_DIV_DEFAULT;
+        e->day_sparse_below = REINA_DAY_SPARSE_DIV_DEFAULT <= 1u ? 0xFFFFFFFFu : cfg->n_agents / REINA_DAY_SPARSE_DIV_DEFAULT;
         if (const char *w = std::getenv("REINA_DAY_SPARSE_DIV")) {
             const int v = std::atoi(w);
             if (v >= 1) e->day_sparse_below = cfg->n_agents / (uint32_t)v;
@@ -281,6 +281,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
             else if (!std::strcmp(w, "sparse")) { e->day_sparse_below = 0xFFFFFFFFu; e->day_flags |= DAY_F_SPARSE_ANY; }
         }
         if (const char *w = std::getenv("REINA_DAY_FLAGS")) e->day_flags |= (uint32_t)std::atoi(w);
+        if (const char *w = std::getenv("REINA_OPEN_TICKETS")) e->open_tickets = std::atoi(w) != 0;   // (the tests' handle on the ticket path of a single engine)
         if (const char *w = std::getenv("REINA_IMPORTS_IN_OPEN")) e->imports_in_open = std::atoi(w) != 0;   // (the round-3 placement, for comparison)
     }
     std::memset(&e->h_params, 0, sizeof(DevParams));
@@ -628,15 +629,16 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     {
         const int helpers = weekly_own == OPEN_WEEKLY_IN_STREAM ? 0 : weekly_own > 0 ? weekly_own : -weekly_own;
         const int g0 = 1 + (helpers > 1 ? helpers : 1), g = g0 + tg;
+        const int open_tickets = (K > 1 || g > (int)e->n_cus || e->open_tickets) ? 1 : 0;   // (roles by arrival ticket unless the launch is resident as a whole)
         if (!e->testing_ever) {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g0, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0);
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g0, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0, open_tickets);
         } else if (ct && N <= 8000000u) {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 3);  // detects + traces, both levels
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 3, open_tickets);  // detects + traces, both levels
         } else if (ct) {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 2);  // detects + traces level 0
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 2, open_tickets);  // detects + traces level 0
             LAUNCH_DAY(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, dp);
         } else {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 1);
+            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 1, open_tickets);
         }
         // a vaccination programme: its pass over the agents comes after the test queue and before the stream
         // (HealthcareSystem.iterate, main.pyx:514-558)

@@ -181,6 +181,26 @@ def test_sparse_and_dense_days_are_the_same_day(mode, monkeypatch):
         _run_and_compare(vv, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
 
 
+@pytest.mark.parametrize('env', ['REINA_OPEN_TICKETS', 'REINA_IMPORTS_IN_OPEN'])
+def test_the_alternative_launch_shapes_of_the_opening_give_the_same_days(env, monkeypatch):
+    """Two choices of round 4 have their older form behind a switch, and both forms must give oracle B's days: the roles of
+    the day-opening launch by block number (a single engine, resident as a whole) or by arrival ticket (engine groups; forced
+    here by REINA_OPEN_TICKETS), and the weekly imports placed beside the stream in k_day's launch or by the opening launch
+    (days with intervention imports; forced by REINA_IMPORTS_IN_OPEN).  Scenarios with weekly imports, tracing at both
+    levels, vaccination and an initial condition."""
+    monkeypatch.setenv(env, '1')
+    _, meta = load_run('mini_kitchen_s3')
+    _run_and_compare(variables_for(meta), np.asarray(meta['age_counts']), meta['seed'], meta['days'], interventions=meta['interventions'])
+    _, meta = load_run('mini_imports_s1')
+    _run_and_compare(variables_for(meta), np.asarray(meta['age_counts']), meta['seed'], meta['days'], interventions=meta['interventions'])
+    for case in (2, 5, 11):
+        rng = np.random.default_rng(1000 + case)
+        vv, ages, days, ivs, ipc = _random_scenario(rng)
+        _run_and_compare(vv, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    _run_and_compare(v, datasets.scaled_population(300000), 3, 250, chunk=125)   # (the default scenario's weekly imports from July on)
+
+
 def test_sparse_dense_and_mixed_years_of_the_hus_population_are_identical(monkeypatch):
     """BASELINE configs[1] (1 685 983 agents x 365 days): the year as run by default (sparse days below 2.5 % active agents,
     dense days above: both forms occur), all days dense and all days sparse give the identical history and final state;
