@@ -629,7 +629,9 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     {
         const int helpers = weekly_own == OPEN_WEEKLY_IN_STREAM ? 0 : weekly_own > 0 ? weekly_own : -weekly_own;
         const int g0 = 1 + (helpers > 1 ? helpers : 1), g = g0 + tg;
-        const int open_tickets = (K > 1 || g > (int)e->n_cus || e->open_tickets) ? 1 : 0;   // (roles by arrival ticket unless the launch is resident as a whole)
+        // roles by arrival ticket unless the launch is resident as a whole -- and, measured, for small populations too
+        // (HUS year: k_open 10.4 us a day with tickets, 11.2 by block number; 10^8 agents: 14.6 against 14.1)
+        const int open_tickets = (K > 1 || g > (int)e->n_cus || e->open_tickets || N <= 8000000u) ? 1 : 0;
         if (!e->testing_ever) {
             LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g0, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0, open_tickets);
         } else if (ct && N <= 8000000u) {

@@ -199,6 +199,10 @@ def test_the_alternative_launch_shapes_of_the_opening_give_the_same_days(env, mo
         _run_and_compare(vv, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
     v = copy.deepcopy(VARIABLE_DEFAULTS)
     _run_and_compare(v, datasets.scaled_population(300000), 3, 250, chunk=125)   # (the default scenario's weekly imports from July on)
+    if env == 'REINA_OPEN_TICKETS':   # (a population above 8 M agents takes the block-number roles by default, level-1 tracing in a launch of its own)
+        import bench
+        vv, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 9_000_000)
+        _run_and_compare(vv, ages, 5, 135, chunk=45)
 
 
 def test_sparse_dense_and_mixed_years_of_the_hus_population_are_identical(monkeypatch):

@@ -19,8 +19,12 @@ def run(agents, days, mode):
     from reina_model_amd import engine as eng
     from reina_model_amd import simulation
     from reina_model_amd.variables import VARIABLE_DEFAULTS
-    os.environ.pop('REINA_DAY_MODE', None)
-    os.environ.pop('REINA_DAY_FLAGS', None)
+    for k in ('REINA_DAY_MODE', 'REINA_DAY_FLAGS', 'REINA_OPEN_TICKETS', 'REINA_IMPORTS_IN_OPEN'):
+        os.environ.pop(k, None)
+    if mode == 'tickets':
+        os.environ['REINA_OPEN_TICKETS'] = '1'
+    if mode == 'imports_open':
+        os.environ['REINA_IMPORTS_IN_OPEN'] = '1' 
     if mode in ('dense', 'sparse'):
         os.environ['REINA_DAY_MODE'] = mode
     if mode == 'hotgather':
