@@ -398,6 +398,9 @@ def main():
     ap.add_argument('--sizes', default='50000000,100000000,200000000',
                     help='synthetic populations of the full_scenario object (HUS is always there)')
     ap.add_argument('--large-agents', type=int, default=50_000_000, help='N > 1: agents per GPU of the `large` object')
+    ap.add_argument('--strong-agents', type=int, default=100_000_000,
+                    help='N > 1: TOTAL agents of the `strong` object (north_star\'s target configuration: 10^8 agents over the ranks)')
+    ap.add_argument('--no-strong', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-sizes', action='store_true', help='skip the full_scenario object')
     ap.add_argument('--no-large', action='store_true')
@@ -459,12 +462,13 @@ def main():
         v, ages = scaled_scenario(v, per_gpu * world)
         workload = 'synthetic %d agents (%d per GPU; HUS age structure + FI contact matrix, beds/ICU/imports scaled), default scenario, days %d..%d' % (
             per_gpu * world, per_gpu, a.warmup, a.warmup + a.steps - 1)
-        traffic_key = str(a.agents) if world == 1 else None
+        traffic_key = str(a.agents) if world == 1 and a.steps == 365 else None
     else:
         ages = datasets.get_population_for_area()
         workload = 'HUS %d agents (BASELINE configs[1]), default scenario (variables.py:227-435), days %d..%d' % (
             HUS_AGENTS, a.warmup, a.warmup + a.steps - 1)
-        traffic_key = 'hus'
+        # (profiles/traffic.json holds the 365-day scenario's mean bytes per day: a shorter window gets no traffic figure)
+        traffic_key = 'hus' if a.steps == 365 else None
 
     def max_over_ranks(dt):
         if world == 1:
@@ -491,6 +495,20 @@ def main():
             'value': round(tot_l * 365 / rl['dt'], 1), 'unit': 'agent-days/s', 'ms_per_step': round(rl['dt'] * 1000 / 365, 6),
             'roofline': roofline_obj(tot_l // world, rl, 365, 16), 'final_all_infected': rl['stats']['final_all_infected'],
         }
+    strong_sharded = None
+    if world > 1 and not a.no_strong and not a.agents:
+        # north_star's target configuration: 10^8 agents in TOTAL over the ranks -- strong scaling of the metric's size
+        # (the N = 1 counterpart is full_scenario["100000000"] of the single-GPU line)
+        vs_, ages_s = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.strong_agents)
+        rs = run_gpu(vs_, ages_s, a.seed, 365, 0, device, dist, preheat=60, stride=16, preheat_runs=1)
+        rs['dt'] = max_over_ranks(rs['dt'])
+        tot_s = int(np.asarray(ages_s).sum())
+        strong_sharded = {
+            'workload': 'synthetic %d agents in total (%d per GPU), default scenario scaled, 365 days' % (tot_s, tot_s // world),
+            'scaling': 'strong', 'value': round(tot_s * 365 / rs['dt'], 1), 'unit': 'agent-days/s',
+            'ms_per_step': round(rs['dt'] * 1000 / 365, 6), 'rccl_world': rs['rccl_world'],
+            'roofline': roofline_obj(tot_s // world, rs, 365, 16), 'final_all_infected': rs['stats']['final_all_infected'],
+        }
     ens_dist = None
     if world > 1 and not a.no_ensemble and not a.agents:
         try:
@@ -515,12 +533,32 @@ def main():
                       'all GPU work of such a day, the table upload included, is inside the timed region'],
         }
         if world > 1:
+            out['notes'].append(
+                'reading the scaling curve: the headline keeps %d agents PER GPU, a size at which a day is a chain of launches at the '
+                'dispatch floor -- a sharded day has two more launches (k_hosp_presort, k_remote) and the all-reduce, about 56 us of '
+                'kernels per shard against 37 unsharded (DESIGN section 6) plus RCCL\'s small-message latency: expect 50-60 %% '
+                'weak-scaling efficiency there by construction.  `large` (5 x 10^7 agents per GPU, BASELINE configs[3]) is the weak-'
+                'scaling figure to read, `strong` (10^8 agents in total, north_star\'s target) the strong-scaling one; its N = 1 '
+                'counterpart is full_scenario["100000000"] of the single-GPU line' % per_gpu)
             # how the per-day exchange ran: ncclCommCount of the communicator the day stream's in-stream all-reduce uses, or null
             # when the direct communicator could not be built and the exchange fell back to torch.distributed.all_reduce
             out['rccl_world'] = res['rccl_world']
             out['config']['rccl_world'] = res['rccl_world']
             out['config']['collective'] = ('ncclAllReduce queued on the day stream (own RCCL communicator)' if res['rccl_world']
                                            else 'torch.distributed.all_reduce (%s backend; direct RCCL communicator unavailable)' % dist.get_backend())
+
+        if world == 1 and not a.agents and a.steps <= 64:
+            # the same window in a process that has NOT seen the scenario's mobility values: every count-threshold row of a
+            # table change inside the window computed afresh (REINA_COUNT_ROW_CACHE=0), GPU warm
+            try:
+                os.environ['REINA_COUNT_ROW_CACHE'] = '0'
+                rc_ = run_gpu(v, ages, a.seed, a.steps, a.warmup, device, None, preheat=0, stride=stride)
+                out['cold_count_rows'] = {'ms_per_step': round(rc_['dt'] * 1000 / a.steps, 6),
+                                          'note': 'the timed window again with the process-wide table of count-threshold rows switched off'}
+            except Exception as e:   # noqa: BLE001
+                out['cold_count_rows'] = {'error': str(e)[:200]}
+            finally:
+                os.environ.pop('REINA_COUNT_ROW_CACHE', None)
 
         def extra(store, key, fn):
             # the additional workloads must not take the headline line down with them
@@ -553,6 +591,8 @@ def main():
                 extra(fs, str(n_cfg), lambda n_cfg=n_cfg: full_line(n_cfg, labels.get(n_cfg, 'synthetic')))
         if large_sharded is not None:
             out['large'] = large_sharded
+        if strong_sharded is not None:
+            out['strong'] = strong_sharded
         if ens_dist is not None:
             out['ensemble'] = ens_dist
         if not a.no_ensemble and world == 1 and not a.agents:

@@ -165,7 +165,11 @@ static void count_row_for(float nr_contacts, uint32_t *thr, uint8_t *guide) {
     static std::unordered_map<uint32_t, CountRow> rows;
     uint32_t key;
     std::memcpy(&key, &nr_contacts, 4);
-    {
+    // (REINA_COUNT_ROW_CACHE=0: every row computed afresh -- what a table change costs a process that has not seen the
+    // scenario's mobility values before; bench.py reports that figure beside the warm one)
+    const char *cache_env = std::getenv("REINA_COUNT_ROW_CACHE");
+    const bool use_cache = !(cache_env && cache_env[0] == '0');
+    if (use_cache) {
         std::lock_guard<std::mutex> g(mu);
         auto it = rows.find(key);
         if (it != rows.end()) {
@@ -183,6 +187,7 @@ static void count_row_for(float nr_contacts, uint32_t *thr, uint8_t *guide) {
     }
     std::memcpy(thr, row.thr, sizeof(row.thr));
     std::memcpy(guide, row.guide, 256);
+    if (!use_cache) return;
     std::lock_guard<std::mutex> g(mu);
     if (rows.size() < 4096) rows.emplace(key, row);
 }
