@@ -606,6 +606,22 @@ def main():
                     out['cpu_baseline']['cpu_model'] = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
             except Exception:
                 pass
+            # how the port relates to the reference it stands for: both timed on one core of the BUILD container over the same days
+            # (tools/cpu_calibration.py, needs /root/reference; a recorded constant here -- the reference never travels)
+            try:
+                cal = json.load(open(os.path.join(ROOT, 'profiles', 'cpu_calibration.json')))
+                r_ = cal['results']
+                out['cpu_baseline']['calibration'] = {
+                    'where': 'build container, %s, one core; %s' % (cal['cpu_model'], cal['workload']),
+                    'oracle_a_agent_days_per_s': {k: x['agent_days_per_s'] for k, x in r_['oracle_a'].items()},
+                    'cythonsim_agent_days_per_s': {k: x['agent_days_per_s'] for k, x in r_['cythonsim'].items()},
+                    'cythonsim_noexcept_build_agent_days_per_s': {k: x['agent_days_per_s'] for k, x in r_['cythonsim_noexcept'].items()},
+                    'port_over_reference_365_days': {
+                        'container Cython (3.2: GIL round trip per cdef nogil call)': round(r_['oracle_a']['365']['agent_days_per_s'] / r_['cythonsim']['365']['agent_days_per_s'], 2),
+                        'legacy_implicit_noexcept build (what the reference pins, cython 3.0a6)': round(r_['oracle_a']['365']['agent_days_per_s'] / r_['cythonsim_noexcept']['365']['agent_days_per_s'], 2)},
+                    'note': 'the port is FASTER than the reference it stands for: divide cpu_baseline.value by the ratio to estimate cythonsim on this host'}
+            except Exception:
+                pass
             if cpu_all is not None:
                 r_all = cpu_all.run()
                 if r_all is not None:
