@@ -84,6 +84,9 @@ enum {
 /* scalar slots following the per-age arrays (Context / HealthcareSystem scalars,
  * main.pyx:452-453,1756; daily_contacts :1341; infected_by_variant :1338) */
 enum {
+    /* (a SHARD's available_* are its contributions to the one pool of the population: admissions are decided against the
+     * pooled count while every shard adds only its own events' changes, so a single shard's value may be negative or
+     * exceed its REINA_S_BEDS -- only the sum over the shards is the hospital's free capacity; model.Context sums them) */
     REINA_S_AVAILABLE_BEDS = 0, REINA_S_AVAILABLE_ICU, REINA_S_BEDS, REINA_S_ICU_UNITS,
     REINA_S_TOTAL_INFECTIONS, REINA_S_TOTAL_INFECTORS, REINA_S_EXPOSED_PER_DAY,
     REINA_S_CT_CASES_PER_DAY, REINA_S_PROBLEM, REINA_S_DAY, REINA_S_UNABLE_TO_IMPORT,

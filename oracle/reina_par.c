@@ -1202,6 +1202,12 @@ void par_test_gamma(float mu, float cv, uint64_t seed, uint32_t day, uint32_t pu
     for (int i = 0; i < n; i++)
         y[i] = rp_gamma_mu_cv(mu, cv, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, day, purpose, 1);
 }
+/* the count one given 32-bit draw yields for an age with `nrc` contacts a day (tests: the "never" encoding of the thresholds) */
+int par_test_count_from_draw(float nrc, int ill, uint32_t r) {
+    uint32_t row[REINA_COUNT_WORDS];
+    rc_count_thresholds(nrc, row);
+    return rc_count_from_draw(row, ill, r);
+}
 void par_test_nr_contacts(uint64_t seed, uint32_t day, float nrc, float factor, int limit, int32_t *y, int n) {
     uint32_t row[REINA_COUNT_WORDS];
     (void)limit;

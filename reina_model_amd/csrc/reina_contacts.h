@@ -47,6 +47,7 @@ static inline int rc_count_from_draw(const uint32_t *row, int ill, uint32_t r) {
     const uint32_t *thr = row + (ill ? REINA_COUNT_FULL : 0);
     const int limit = ill ? REINA_COUNT_ILL : REINA_COUNT_FULL;
     int n = 0;
+    if (r == 0xFFFFFFFFu) r = 0xFFFFFFFEu;   // (0xFFFFFFFF is the thresholds' "never": rp_count_draw never returns it either)
     while (n < limit && r >= thr[n]) n++;
     return n;
 }

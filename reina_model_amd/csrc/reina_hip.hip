@@ -364,12 +364,14 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
                                      (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_presort<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)((size_t)HOSP_P_THREADS * HOSP_P_E * 8)), free_engine(e));
+    // (both instantiations of every day kernel that takes dynamic LDS, sized for the larger of its two launch shapes)
+    const size_t walk_lds = (size_t)HOSP_P_THREADS * HOSP_P_E * 8, small_lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_presort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds), free_engine(e));
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_presort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds), free_engine(e));
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)((size_t)REINA_MAX_HOSP_EVENTS * 8)), free_engine(e));
+                                     (int)(walk_lds > small_lds ? walk_lds : small_lds)), free_engine(e));
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)((size_t)REINA_MAX_HOSP_EVENTS * 8)), free_engine(e));
+                                     (int)(walk_lds > small_lds ? walk_lds : small_lds)), free_engine(e));
     *out = e;
     return REINA_OK;
 }

@@ -336,6 +336,7 @@ class Context:
         self._pending_icu = 0
         self._keep = []
         self._iv_index = None
+        self._iv_version = 0
         # sharded with a communicator of our own: the engine queues the pressure all-reduce itself
         self._in_stream = self._direct is not None and (self.n_shards > 1 or self.always_collective)
         if self._in_stream:
@@ -393,8 +394,21 @@ class Context:
         d = date.fromisoformat(self.start_date)
         return (d + timedelta(days=self.day)).isoformat()
 
+    @staticmethod
+    def _iv_date(iv):
+        """An intervention's date as a datetime.date.  The reference compares iv.date with today's ISO string
+        (main.pyx:2014), so a date written any other way silently never applies there; here it is an error, raised
+        when the intervention is added (round-3 advisor finding: it used to surface from the first day of the run)."""
+        ds = str(iv.date)
+        try:
+            return date.fromisoformat(ds)
+        except ValueError:
+            raise ValueError('intervention %r: date %r is not an ISO date (YYYY-MM-DD)' % (getattr(iv, 'type', iv), ds)) from None
+
     def add_intervention(self, iv):
+        self._iv_date(iv)
         self.interventions.append(iv)
+        self._iv_version += 1   # (the by-day index of _build_day is rebuilt)
 
     def find_variant(self, variant_str):
         if variant_str is None:
@@ -470,12 +484,14 @@ class Context:
         # (this function is host time per day, and a short run is host-bound -- DESIGN section 5: the interventions are indexed
         # by day number, a population that is not sharded splits nothing, and without a weekly import flow its float32
         # leftovers stay what they are: below 1, so no import either)
-        if self._iv_index is None or self._iv_index[0] != len(self.interventions):
+        ivs = self.interventions
+        stamp = (len(ivs), self._iv_version, id(ivs[0]) if ivs else 0, id(ivs[-1]) if ivs else 0)
+        if self._iv_index is None or self._iv_index[0] != stamp:
             self._date0 = date.fromisoformat(self.start_date)
             by_day = {}
-            for iv in self.interventions:  # list order is kept within a date (main.pyx:2013-2015)
-                by_day.setdefault((date.fromisoformat(str(iv.date)) - self._date0).days, []).append(iv)
-            self._iv_index = (len(self.interventions), by_day)
+            for iv in ivs:  # list order is kept within a date (main.pyx:2013-2015)
+                by_day.setdefault((self._iv_date(iv) - self._date0).days, []).append(iv)
+            self._iv_index = (stamp, by_day)
         if self.day >= _eng.MAX_DAYS:
             raise SimulationFailed('Day counter overflow: the engine simulates at most %d days' % _eng.MAX_DAYS)
         for iv in self._iv_index[1].get(self.day, ()):

@@ -109,7 +109,7 @@ def test_day_descriptors_follow_the_schedule():
 
 def test_interventions_are_found_by_day_number_whatever_carries_their_date():
     """the schedule is indexed by day number (not by comparing date strings every day): an ISO string and a datetime.date land
-    on the same day, list order within a date is kept, a date before the start never applies, a malformed date is an error"""
+    on the same day, list order within a date is kept, a date before the start never applies, a malformed date is an error when the intervention is added"""
     from datetime import date
     from reina_model_amd.interventions import Intervention
     v = copy.deepcopy(VARIABLE_DEFAULTS)
@@ -124,9 +124,13 @@ def test_interventions_are_found_by_day_number_whatever_carries_their_date():
         ctx.day += 1
         adds.append(d.add_beds)
     assert adds == [0, 0, 12, 0]
-    ctx.add_intervention(Intervention('build-new-hospital-beds', '20/02/2020', {'beds': 1}))
-    with pytest.raises(ValueError):
-        ctx._build_day()
+    with pytest.raises(ValueError, match='not an ISO date'):   # (refused when it is added, not on the first day of the run)
+        ctx.add_intervention(Intervention('build-new-hospital-beds', '20/02/2020', {'beds': 1}))
+    # the index follows the list: an intervention added later, or put in place of another one, is found
+    ctx.add_intervention(Intervention('build-new-hospital-beds', '2020-02-23', {'beds': 3}))
+    ctx.interventions[-1] = Intervention('build-new-hospital-beds', '2020-02-22', {'beds': 4})
+    d, _ = ctx._build_day()
+    assert d.add_beds == 4
 
 
 def test_unknown_intervention_type_raises_like_the_reference():

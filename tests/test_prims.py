@@ -137,3 +137,21 @@ def test_contact_count_matches_reference_samples(L, age):
     assert abs(y.mean() - ref.mean()) < 4 * ref.std() / np.sqrt(len(ref)) + 0.02
     for q in (10, 50, 90, 99):
         assert abs(np.percentile(y, q) - np.percentile(ref, q)) <= max(1.0, 0.06 * np.percentile(ref, q))
+
+
+def test_an_age_without_contacts_never_draws_one(L):
+    """A count row of an age with nr_contacts_by_age <= 0 is all 0xFFFFFFFF ("never": the reference returns 0 contacts for
+    it, main.pyx:1311-1320 with c = 0) and the searches test r >= threshold: the draw r = 0xFFFFFFFF must not pass it
+    (round-3 advisor finding: it returned the full limit of 100 contacts, once in 2^32 draws)."""
+    L.par_test_count_from_draw.argtypes = [ctypes.c_float, ctypes.c_int, ctypes.c_uint32]
+    L.par_test_count_from_draw.restype = ctypes.c_int
+    for r in (0, 1, 0x7FFFFFFF, 0xFFFFFFFE, 0xFFFFFFFF):
+        assert L.par_test_count_from_draw(0.0, 0, r) == 0
+        assert L.par_test_count_from_draw(-1.0, 1, r) == 0
+    # an ordinary age: the largest draw gives the largest count the thresholds allow, monotone in the draw
+    prev = 0
+    for r in (0, 0x40000000, 0x80000000, 0xC0000000, 0xFFFFFFFE, 0xFFFFFFFF):
+        n = L.par_test_count_from_draw(11.5, 0, r)
+        assert n >= prev
+        prev = n
+    assert L.par_test_count_from_draw(11.5, 0, 0xFFFFFFFF) == L.par_test_count_from_draw(11.5, 0, 0xFFFFFFFE)
