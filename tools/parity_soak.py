@@ -15,6 +15,7 @@ if len(sys.argv) > 2 and sys.argv[2] == 'sharded':
     for case in range(n):
         rng = np.random.default_rng(300000 + OFF + case)
         v, ages, days, ivs, ipc = T._random_scenario(rng)
+        os.environ['REINA_DAY_MODE'] = ('dense', 'sparse')[case % 2]   # (round 4: both forms of k_day's stream; small populations would all be dense)
         G = int(rng.integers(2, 5))
         seed = int(rng.integers(0, 2 ** 31))
         if ipc is not None and v['hospital_beds'] == 0 and ipc.get('in_icu', 0) > 0:
@@ -48,6 +49,7 @@ for case in range(n):
     for kind, seed0 in (('random', 100000), ('extreme', 200000)):
         rng = np.random.default_rng(seed0 + OFF + case)
         v, ages, days, ivs, ipc = T._random_scenario(rng)
+        os.environ['REINA_DAY_MODE'] = ('dense', 'sparse')[(case + (kind == 'extreme')) % 2]   # (round 4: both forms of k_day's stream)
         try:
             if kind == 'extreme':
                 total = int(rng.integers(600, 6000))
