@@ -762,7 +762,7 @@ def test_config3_at_full_size_eight_shards_of_fifty_million():
     """BASELINE configs[3] at its stated size on ONE GPU: 4 x 10^8 agents as 8 in-process shards of 5 x 10^7
     (about 40 GB of HBM), stepped in lock-step with the pressure buffers summed in between.  The first 40
     days bit for bit against oracle B sharded the same way (per-shard counter blocks; the imports are
-    scaled with the population, so thousands are infected by then), then on through the first wave:
+    scaled with the population, so thousands are infected by then), then on through all 365 days:
     conservation over the shards, no problem flag, capacities of the cross-shard candidate region, the
     mirror table and the bed-event lists hold."""
     import bench
@@ -789,15 +789,21 @@ def test_config3_at_full_size_eight_shards_of_fifty_million():
     A = eng.MAX_AGES
     n = int(np.asarray(ages).sum())
     tot = None
-    for d in range(40, 130):
+    # ... and on through the WHOLE year (round 4: sparse days make it cheap): the first wave, tracing from day 118, the weekly
+    # imports, the autumn wave -- conservation over the shards, hospital identities, no problem flag on any shard
+    for d in range(40, 365):
         sharding.step_shards_together(gpu)
-        if d % 30 == 9 or d == 129:
+        if d % 30 == 9 or d == 129 or d == 364:
             c = sharding.reduce_counters(gpu)
             tot = lambda name: int(c[eng.C_NAMES.index(name) * A:(eng.C_NAMES.index(name) + 1) * A].astype(np.int64).sum())
             assert tot('susceptible') + tot('infected') + tot('recovered') + tot('dead') == n, d
+            assert tot('all_infected') == tot('infected') + tot('recovered') + tot('dead'), d
+            assert tot('hospitalized') == tot('in_ward') + tot('in_icu'), d
             for ctx in gpu:
                 ctx._raise_on_problem(ctx.engine.read_counters())
-    assert tot('all_infected') > 20_000_000
+            if d == 129:
+                assert tot('all_infected') > 20_000_000
+    assert tot('all_infected') > 60_000_000 and tot('all_detected') > 20_000_000
 
 
 def test_config2_fifty_million_agents_against_oracle_b():
