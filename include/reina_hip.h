@@ -403,6 +403,11 @@ int reina_group_run_days(reina_group_t *g, const reina_day_t *days, uint32_t n_d
 /* replaces Context.generate_state's reads (main.pyx:1813-1857): copies the counter block to host
  * (synchronises `stream`) */
 int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream);
+/* the end of a run (calc/simulation.py:194-290: the rows the loop collected, then the final state): copies the `n_rows`
+ * history rows at `history_dev` (as written by reina_run_days_hist) and, behind them as row n_rows, the counter block as it
+ * stands, to `out_host` [(n_rows + 1) * REINA_COUNTER_WORDS] -- page-locked memory makes it one DMA --, and synchronises
+ * `stream`: one call, two copies, one wait */
+int reina_read_history(reina_engine_t *e, const int32_t *history_dev, uint32_t n_rows, int32_t *out_host, void *stream);
 /* timing hooks for bench.py: HIP events on the launch stream around the day's kernels (start / stop
  * timestamps of the kernel's own dispatch packet).
  * enable: 0 off; 1 every kernel of every day; k >= 4: one KIND of kernel per profiled day, the kinds taking

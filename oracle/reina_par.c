@@ -1168,6 +1168,12 @@ int par_read_counters(Par *e, int32_t *out, void *stream) {
     memcpy(out, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
     return 0;
 }
+int par_read_history(Par *e, const int32_t *history, uint32_t n_rows, int32_t *out, void *stream) {
+    (void)stream;
+    if (n_rows) memcpy(out, history, sizeof(int32_t) * REINA_COUNTER_WORDS * (size_t)n_rows);
+    memcpy(out + (size_t)n_rows * REINA_COUNTER_WORDS, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
+    return 0;
+}
 int par_profile_enable(Par *e, int en) { (void)e; (void)en; return 0; }
 int par_profile_read(Par *e, double *a, uint64_t *b, double *c) { (void)e; *a = 0; *b = 0; *c = 0; return 0; }
 int par_profile_read_kernels(Par *e, double *ms, uint64_t *n) {

@@ -892,6 +892,17 @@ int reina_read_counters(reina_engine_t *e, int32_t *out_host, void *stream) {
     return REINA_OK;
 }
 
+int reina_read_history(reina_engine_t *e, const int32_t *history_dev, uint32_t n_rows, int32_t *out_host, void *stream) {
+    if (!e || !out_host || (n_rows && !history_dev)) return REINA_E_INVALID;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row = sizeof(int32_t) * REINA_COUNTER_WORDS;
+    if (n_rows) HIP_CHECK(hipMemcpyAsync(out_host, history_dev, row * n_rows, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(out_host + (size_t)n_rows * REINA_COUNTER_WORDS, e->buf.counters, row, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return REINA_OK;
+}
+
 int reina_profile_enable(reina_engine_t *e, int enable) {
     if (!e) return REINA_E_INVALID;
     e->profile = enable != 0;

@@ -52,7 +52,7 @@ COLD_FIELDS = dict(infector=2, n_infected=3, onset_days=4, vacc_day=5, first_inf
 PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install')
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
-                 'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'profile_enable', 'profile_read',
+                 'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'read_history', 'profile_enable', 'profile_read',
                  'profile_read_kernels',
                  'group_create', 'group_destroy', 'group_upload_contact_tables', 'group_run_days',
                  'build_contact_tables', 'test_prims', 'last_error', 'abi_version')
@@ -195,6 +195,7 @@ def bind_abi(lib, prefix):
     f['run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp]
     f['run_days_hist'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp, vp]
     f['read_counters'].argtypes = [vp, vp, vp]
+    f['read_history'].argtypes = [vp, vp, ctypes.c_uint32, vp, vp]
     f['group_create'].argtypes = [ctypes.POINTER(vp), ctypes.c_uint32, ctypes.POINTER(vp)]
     f['group_destroy'].argtypes = [vp]
     f['group_upload_contact_tables'].argtypes = [vp, ctypes.POINTER(ContactTablesABI), vp]
@@ -438,6 +439,22 @@ class Engine:
         out = np.zeros(COUNTER_WORDS, dtype=np.int32)
         self._check(self.f['read_counters'](self._h, out.ctypes.data, self.alloc.stream()), 'read_counters')
         return out
+
+    def read_history(self, hist, rows):
+        """the `rows` history rows in `hist` (device) and, behind them, the counter block as it stands: one library call -- two
+        copies into page-locked memory and one wait (torch's slicing, copy_ and synchronize around the same bytes took 68 us of
+        a 20-day window's 740)"""
+        n = (rows + 1) * COUNTER_WORDS
+        t = getattr(self.alloc, 'torch', None)
+        if t is None:
+            out = np.zeros(n, dtype=np.int32)
+            ptr = out.ctypes.data
+        else:
+            pin = t.empty(n, dtype=t.int32, pin_memory=True)   # (the caching host allocator hands the block of the last run back)
+            out = pin.numpy()
+            ptr = pin.data_ptr()
+        self._check(self.f['read_history'](self._h, self.alloc.ptr(hist), int(rows), ptr, self.alloc.stream()), 'read_history')
+        return out.reshape(rows + 1, COUNTER_WORDS)
 
     def sample(self, disease, seed, what, age, severity, nrc, n):
         out = np.zeros(n, dtype=np.int32)

@@ -616,14 +616,12 @@ class Context:
         return None
 
     def _history_buffer(self, days):
-        """`days` history rows (each written whole by its day's opening launch: no memset) + one for the counters after the
-        last day, so that rows and problem flag come back in ONE copy and one wait"""
-        return self.engine.alloc.empty((days + 1) * _eng.COUNTER_WORDS, np.int32)
+        """`days` history rows (each written whole by its day's opening launch: no memset); they come back together with the
+        counters after the last day in one library call (engine.read_history)"""
+        return self.engine.alloc.empty(max(days, 1) * _eng.COUNTER_WORDS, np.int32)
 
     def _history_to_host(self, hist, days):
-        a = self.engine.alloc
-        a.copy_into(hist, days * _eng.COUNTER_WORDS, self.engine.tensors['counters'])
-        out = a.to_host(hist).reshape(days + 1, _eng.COUNTER_WORDS)
+        out = self.engine.read_history(hist, days)
         self._raise_on_problem(out[days])
         return out[:days]
 
