@@ -1208,6 +1208,16 @@ void par_test_gamma(float mu, float cv, uint64_t seed, uint32_t day, uint32_t pu
     for (int i = 0; i < n; i++)
         y[i] = rp_gamma_mu_cv(mu, cv, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, day, purpose, 1);
 }
+/* the saturating-map algebra of the bed / ICU walk (csrc/reina_prims.h: rp_sat_*), for tests that hold it against the plain
+ * definition f(x) = max(x + a, m): out = {then.a, then.m, apply(then, x), packed-and-unpacked bed map a, m, ICU map a, m} */
+void par_test_sat(int a1, int m1, int a2, int m2, int x, int *out) {
+    rp_sat_t f, g, fb, fc;
+    f.a = a1; f.m = m1; g.a = a2; g.m = m2;
+    const rp_sat_t h = rp_sat_then(f, g);
+    out[0] = h.a; out[1] = h.m; out[2] = rp_sat_apply(h, x);
+    rp_sat_unpack(rp_sat_pack(f, g), &fb, &fc);
+    out[3] = fb.a; out[4] = fb.m; out[5] = fc.a; out[6] = fc.m;
+}
 /* the count one given 32-bit draw yields for an age with `nrc` contacts a day (tests: the "never" encoding of the thresholds) */
 int par_test_count_from_draw(float nrc, int ill, uint32_t r) {
     uint32_t row[REINA_COUNT_WORDS];

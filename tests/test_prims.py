@@ -155,3 +155,50 @@ def test_an_age_without_contacts_never_draws_one(L):
         assert n >= prev
         prev = n
     assert L.par_test_count_from_draw(11.5, 0, 0xFFFFFFFF) == L.par_test_count_from_draw(11.5, 0, 0xFFFFFFFE)
+
+
+def test_saturating_maps_compose_like_the_functions_they_stand_for(L):
+    """The ordered bed / ICU walk -- and what a sharded population's shards exchange -- rests on one piece of algebra shared by
+    the kernels and oracle B (csrc/reina_prims.h): an event acts on a free count as f(x) = max(x + a, m), and two such maps
+    compose to one of the same form.  Held here against the plain definition, evaluated in Python integers: random chains of
+    admissions (a = -1, m = 0), releases (a = +1, never binds) and composed maps, applied to every free count from 0 to 40;
+    composition is associative; a bucket's pair of maps survives its 57-bit packing (round-3 verdict: the algebra was held
+    only by the statistical tier)."""
+    L.par_test_sat.argtypes = [ctypes.c_int] * 5 + [vp]
+    NEG = -(1 << 29)
+    out = (ctypes.c_int * 7)()
+
+    def then(f, g):
+        L.par_test_sat(f[0], f[1], g[0], g[1], 0, out)
+        return (out[0], out[1])
+
+    def apply_c(f, x):
+        L.par_test_sat(0, NEG, f[0], f[1], x, out)   # identity, then f
+        return out[2]
+
+    ev = {'take': (-1, 0), 'give': (1, NEG)}
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        chain = [ev['take'] if rng.random() < 0.6 else ev['give'] for _ in range(int(rng.integers(1, 60)))]
+        # the chain composed left to right, and in a random bracketing (associativity)
+        acc = (0, NEG)
+        for f in chain:
+            acc = then(acc, f)
+        cut = int(rng.integers(0, len(chain) + 1))
+        left, right = (0, NEG), (0, NEG)
+        for f in chain[:cut]:
+            left = then(left, f)
+        for f in chain[cut:]:
+            right = then(right, f)
+        assert then(left, right) == acc
+        for x in range(0, 41):
+            y = x
+            for a, m in chain:        # the definition, event by event: take one if any, give one back
+                y = max(y + a, m)
+            assert apply_c(acc, x) == y, (chain, x)
+        # packing: what a walker publishes / a shard sends for a bucket (|a|, |m| <= 4096, or "never binds")
+        if -4096 <= acc[0] <= 4096 and (acc[1] <= NEG // 2 or -4096 <= acc[1] <= 4096):
+            L.par_test_sat(acc[0], acc[1], left[0], left[1], 0, out)
+            for got, want in (((out[3], out[4]), acc), ((out[5], out[6]), left)):
+                assert got[0] == want[0]
+                assert got[1] == want[1] or (got[1] <= NEG // 2 and want[1] <= NEG // 2)
