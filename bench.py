@@ -530,7 +530,13 @@ def main():
                       'on a day whose contact tables change, the host-side count-threshold rows of values seen before in this '
                       'process (the untimed warm-up runs of the same scenario) are taken from a process-wide table instead of '
                       'being recomputed (reina_hip.hip count_row_for; 83 us of host time per table change, DESIGN section 5); '
-                      'all GPU work of such a day, the table upload included, is inside the timed region'],
+                      'all GPU work of such a day, the table upload included, is inside the timed region',
+                      'roofline.achieved / frac price the day at its ALGORITHMIC bytes (SURVEY 8d: every agent\'s 4-byte hot word once a '
+                      'day, ...).  Since round 4 a population of >= 4 tiles per wave (about 8 M agents on a whole chip) does not read them: '
+                      'k_day streams one ACTIVE bit per agent and fetches the words of the agents whose bit is set (the reference leaves '
+                      'everybody who is not infected at once too, main.pyx:1974-1975), so the HBM bytes actually moved -- roofline.traffic, '
+                      'PMC counters -- are about half the algorithmic ones at 5e7-2e8 agents, and a frac near or above 1 on a quiet day '
+                      'means "faster than a perfect stream of the hot words would be", not a measurement error'],
         }
         if world > 1:
             out['notes'].append(
