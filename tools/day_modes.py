@@ -1,5 +1,5 @@
 """Per-day kernel times of one scenario with k_day forced dense, forced sparse, and choosing by itself (round 4).
-usage: python tools/day_modes.py [agents] [days] [modes...]    (modes: dense sparse auto hotgather; default all)
+usage: python tools/day_modes.py [agents] [days] [modes...]    (modes: dense sparse auto tickets imports_open; default: dense sparse auto)
 Each day is stepped alone and every kernel of it timed (HIP events, profile stride 1), so the times carry the event
 overhead of a fully timed day (a few us) -- the comparison between modes is what this is for: from which share of active
 agents on does streaming the hot words beat fetching the active ones (REINA_DAY_SPARSE_DIV_DEFAULT)?"""
@@ -27,9 +27,6 @@ def run(agents, days, mode):
         os.environ['REINA_IMPORTS_IN_OPEN'] = '1' 
     if mode in ('dense', 'sparse'):
         os.environ['REINA_DAY_MODE'] = mode
-    if mode == 'hotgather':
-        os.environ['REINA_DAY_MODE'] = 'dense'
-        os.environ['REINA_DAY_FLAGS'] = '1'
     v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), agents)
     ctx = simulation.make_context(v, age_counts=ages, seed=0)
     ctx.engine.profile_enable(1)
@@ -48,7 +45,7 @@ if __name__ == '__main__':
     import numpy as np
     agents = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
     days = int(sys.argv[2]) if len(sys.argv) > 2 else 365
-    modes = sys.argv[3:] or ['dense', 'sparse', 'auto', 'hotgather']
+    modes = sys.argv[3:] or ['dense', 'sparse', 'auto']
     out, finals = {}, {}
     for m in modes:
         out[m], finals[m] = run(agents, days, m)
