@@ -179,17 +179,34 @@ def lib_sha256():
     return h.hexdigest()
 
 
+def src_sha256():
+    """sha256 over the sources the library is built from (csrc/*, include/reina_hip.h), in name order: the second way a
+    traffic.json is matched to the tree -- hipcc's builds of identical sources differ in a build id"""
+    from reina_model_amd import build as _b
+    h = hashlib.sha256()
+    for f in sorted(set(_b.DEPS)):
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def traffic_for(key):
     """HBM bytes per day from the PMC passes, only if collected on this very binary"""
     try:
         tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
     except Exception:
         return None, 'no profiles/traffic.json'
-    if tj.get('lib_sha256') != lib_sha256():
-        return None, 'profiles/traffic.json was collected on another binary (sha256 %s..., commit %s): not reported' % (
+    how = None
+    if tj.get('lib_sha256') == lib_sha256():
+        how = 'the binary being timed (sha256 match)'
+    elif tj.get('src_sha256') and tj.get('src_sha256') == src_sha256():
+        how = 'a build of the very sources this binary was built from (sha256 over csrc/ and include/ matches; the binary was rebuilt since)'
+    if how is None:
+        return None, 'profiles/traffic.json was collected on another binary (sha256 %s..., commit %s) and other sources: not reported' % (
             str(tj.get('lib_sha256'))[:12], tj.get('commit'))
     val = tj.get('per_day_bytes', {}).get(key)
-    return val, 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the kernels of a day, mean over the scenario; commit %s' % tj.get('commit')
+    return val, 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the kernels of a day, mean over the scenario; collected on %s; commit %s' % (how, tj.get('commit'))
 
 
 def roofline_obj(n_agents, res, steps, stride, traffic_key=None):

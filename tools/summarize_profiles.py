@@ -118,7 +118,9 @@ if per_day and os.path.exists(sha_f):
         commit = subprocess.check_output(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD']).decode().strip()
     except Exception:
         commit = None
-    json.dump({'lib_sha256': open(sha_f).read().strip(), 'commit': commit, 'tag': tag, 'per_day_bytes': per_day,
+    sys.path.insert(0, ROOT)
+    import bench as _bench
+    json.dump({'lib_sha256': open(sha_f).read().strip(), 'src_sha256': _bench.src_sha256(), 'commit': commit, 'tag': tag, 'per_day_bytes': per_day,
                'per_kernel_bytes_per_day': per_kernel,
                '_comment': 'HBM bytes per simulated day summed over every kernel of the day: rocprofv3 --pmc FETCH_SIZE and '
                            '--pmc WRITE_SIZE (separate passes, --kernel-trace only) over one 365-day scenario; FETCH_SIZE (KB) '
