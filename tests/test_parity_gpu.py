@@ -181,6 +181,22 @@ def test_sparse_and_dense_days_are_the_same_day(mode, monkeypatch):
         _run_and_compare(vv, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
 
 
+def test_a_threshold_on_yesterdays_active_agents_mixes_sparse_and_dense_days(monkeypatch):
+    """REINA_DAY_SPARSE_DIV = d: a day of a large population is sparse only while yesterday's stream queued fewer than n / d
+    agents (the kernel keeps the count in two control words by day parity).  9 M agents through the first wave with d = 40:
+    sparse days, then dense ones from 2.5 % active agents on, then sparse again -- oracle B's days bit for bit."""
+    import bench
+    monkeypatch.setenv('REINA_DAY_SPARSE_DIV', '40')
+    vv, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 9_000_000)
+    gpu, cpu = _run_and_compare(vv, ages, 8, 150, chunk=50)
+    ctl = gpu.engine.alloc.to_host(gpu.engine.tensors['control'])
+    c = gpu.per_age_counters()
+    # the count the switch reads (REINA_L_ACTIVE, words 24-25 by day parity): day 149's stream queued every infected agent and
+    # every removed one not yet counted into R
+    assert int(ctl[24 + 1]) >= int(c['infected'].sum()) - int(c['new_infections'].sum()) > 0
+    assert c['all_infected'].sum() > 9_000_000 // 10   # (the wave went well above the 2.5 % threshold)
+
+
 @pytest.mark.parametrize('env', ['REINA_OPEN_TICKETS', 'REINA_IMPORTS_IN_OPEN'])
 def test_the_alternative_launch_shapes_of_the_opening_give_the_same_days(env, monkeypatch):
     """Two choices of round 4 have their older form behind a switch, and both forms must give oracle B's days: the roles of
