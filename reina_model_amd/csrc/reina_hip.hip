@@ -685,7 +685,9 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
             if (ig > (int)e->n_cus) ig = (int)e->n_cus;
         }
         // (groups: 128 workgroups for all members together -- every workgroup pays its prologue and its histogram flush)
-        if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 2;
+        // (a group of 128 HUS members, measured in round 4: ONE installing workgroup per member beside the one for the events --
+        // 256 workgroups, one per CU, all resident together -- 67 us a launch against 72.5 with two, 70 with three)
+        if (K > 1 && ig > (int)(128 / K)) ig = (int)(128 / K) >= 2 ? ((int)(128 / K) & ~1) : 1;
         const bool par = e->h_params.hosp_parallel != 0;
         if (par) {
             // a large population: the launch's first workgroups are the walkers of a day on which the events' order matters
@@ -700,7 +702,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
                          (size_t)HOSP_P_THREADS * HOSP_P_E * 8, s, dp, scan_waves, scan_tiles, HI_INSTALL | HI_EVENTS, n_walk);
         } else {
             // workgroup 0 walks the bed / ICU events of a day on which order matters, beside the installs
-            if (ig < 2) ig = 2;
+            if (ig < 2 && K == 1) ig = 2;
             LAUNCH_DAY(e, today, REINA_PK_INSTALL, k_hosp_install, dim3(ig + 1, K), dim3(HOSP_THREADS), (size_t)REINA_MAX_HOSP_EVENTS * 8, s, dp, scan_waves, scan_tiles, HI_HOSP_WG | HI_INSTALL | HI_EVENTS, 0u);
         }
     }
