@@ -1218,6 +1218,16 @@ void par_test_sat(int a1, int m1, int a2, int m2, int x, int *out) {
     rp_sat_unpack(rp_sat_pack(f, g), &fb, &fc);
     out[3] = fb.a; out[4] = fb.m; out[5] = fc.a; out[6] = fc.m;
 }
+/* rp_chance against its integer form (csrc/reina_prims.h: rp_chance_threshold; k_day tests a source's thinning bound that
+ * way): n (probability bits, draw) pairs -> the number of pairs on which the two disagree */
+int par_test_chance_threshold(const uint32_t *p_bits, const uint32_t *r, int n) {
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        const float p = rp_u2f(p_bits[i]);
+        bad += (rp_chance(p, r[i]) != 0) != ((r[i] >> 8) < rp_chance_threshold(p));
+    }
+    return bad;
+}
 /* the count one given 32-bit draw yields for an age with `nrc` contacts a day (tests: the "never" encoding of the thresholds) */
 int par_test_count_from_draw(float nrc, int ill, uint32_t r) {
     uint32_t row[REINA_COUNT_WORDS];

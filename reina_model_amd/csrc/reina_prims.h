@@ -40,6 +40,13 @@ typedef struct { uint32_t v[4]; } rp_u4;
 #define RP_PHILOX_W0 0x9E3779B9u
 #define RP_PHILOX_W1 0xBB67AE85u
 
+// a ^ b ^ c: on the GPU one instruction (gfx950: v_bitop3_b32, truth table 0x96) -- the compiler keeps two v_xor_b32 when one
+// operand is a round key in a scalar register, a third of a Philox2x32 round's vector instructions
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RP_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#else
+#define RP_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#endif
 RP_HD rp_u4 rp_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
 #if defined(__HIPCC__)
 #pragma unroll
@@ -47,9 +54,9 @@ RP_HD rp_u4 rp_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32
     for (int r = 0; r < 10; r++) {
         uint64_t p0 = (uint64_t)RP_PHILOX_M0 * c0;
         uint64_t p1 = (uint64_t)RP_PHILOX_M1 * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n0 = RP_XOR3((uint32_t)(p1 >> 32), c1, k0);
         uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n2 = RP_XOR3((uint32_t)(p0 >> 32), c3, k1);
         uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += RP_PHILOX_W0;
@@ -73,7 +80,7 @@ RP_HD rp_u2 rp_philox2(uint32_t key, uint32_t c0, uint32_t c1) {
 #endif
     for (int r = 0; r < 10; r++) {
         uint64_t p = (uint64_t)RP_PHILOX2_M * c0;
-        c0 = (uint32_t)(p >> 32) ^ key ^ c1;
+        c0 = RP_XOR3((uint32_t)(p >> 32), c1, key);
         c1 = (uint32_t)p;
         key += RP_PHILOX_W0;
     }
@@ -120,6 +127,17 @@ RP_HD int rp_chance(float p, uint32_t r) {
     if (p == 1.0f) return 1;
     if (p == 0.0f) return 0;
     return rp_uniform24(r) < p;
+}
+// The same decision as one integer comparison: rp_chance(p, r) == ((r >> 8) < rp_chance_threshold(p)) for every p and r.
+// p <= 0, -0 or NaN: never (threshold 0); p >= 1: always (2^24, above every 24-bit draw); between: u x 2^-24 < p is
+// u < p x 2^24 (a power-of-two scaling, exact), i.e. u < ceil(p x 2^24) for an integer u.  For a probability that is tested
+// against many draws (k_day: the thinning bound of a source, once per contact).  tests/test_prims.py checks the identity.
+RP_HD uint32_t rp_chance_threshold(float p) {
+    if (!(p > 0.0f)) return 0u;
+    if (p >= 1.0f) return 1u << 24;
+    const float s = p * 16777216.0f;
+    const uint32_t f = (uint32_t)s;
+    return (float)f < s ? f + 1u : f;
 }
 
 // ------------------------------------------------------------------ exp / log (float, reproducible)

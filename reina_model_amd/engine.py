@@ -339,7 +339,7 @@ class Engine:
             # the day's bed / ICU events by priority range: [bucket counts][bucket aggregates][keys]
             hosp_events=a.zeros(hosp_event_words(n, config.max_hosp_events, config.hosp_ranges), np.uint64),
             pressure=a.zeros(exchange_words(config.n_shards, config.hosp_ranges or hosp_ranges(n)), np.int32),
-            mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 64, np.uint64),   # (unsharded: scratch of the diagnostic builds)
+            mirror=a.zeros(MAX_RANGES * MAX_VARIANTS * config.mirror_slots if config.n_shards > 1 else 64 + 4 * 8192, np.uint64),   # (unsharded: scratch of the diagnostic builds, one row per wave of k_day)
             mirror_meta=a.zeros(2 * MAX_RANGES * MAX_VARIANTS, np.uint32),
             work_counts=a.zeros(5 * MAX_SCAN_WAVES, np.uint32),
             scan_lists=a.zeros(4 * config.max_work_items, np.uint32),

@@ -157,6 +157,41 @@ def test_an_age_without_contacts_never_draws_one(L):
     assert L.par_test_count_from_draw(11.5, 0, 0xFFFFFFFF) == L.par_test_count_from_draw(11.5, 0, 0xFFFFFFFE)
 
 
+def test_a_chance_is_one_integer_comparison(L):
+    """k_day tests every contact's transmission draw against its source's thinning bound as (draw >> 8) < threshold with the
+    threshold computed once per source (csrc/reina_prims.h: rp_chance_threshold); oracle B calls rp_chance, the definition
+    (RandomPool.chance, simrandom.pyx:32-39).  The two must agree on every probability and every draw: probabilities at and
+    around 0 and 1, negative, NaN, infinite, denormal, the neighbours of k x 2^-24 (where the ceiling steps), random bit
+    patterns; draws at the threshold, one below, one above and at random."""
+    L.par_test_chance_threshold.argtypes = [vp, vp, ctypes.c_int]
+    L.par_test_chance_threshold.restype = ctypes.c_int
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 2.0, np.nan, np.inf, -np.inf, 1e-45, 1e-38, 5.96e-8, 0.5, 0.25, 1.0 - 2.0 ** -24,
+                        np.nextafter(np.float32(1), np.float32(0)), np.nextafter(np.float32(1), np.float32(2))], dtype=np.float32)
+    k = rng.integers(0, 1 << 24, 4000).astype(np.float64)
+    edges = (k * 2.0 ** -24).astype(np.float32)
+    near = np.concatenate([edges, np.nextafter(edges, np.float32(0)), np.nextafter(edges, np.float32(1))])
+    rand_bits = rng.integers(0, 1 << 32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    unit = rng.random(20000).astype(np.float32)
+    small = (rng.random(5000) * 1e-6).astype(np.float32)
+    ps = np.concatenate([special, near, rand_bits, unit, small]).astype(np.float32)
+    # per probability: draws whose 24 bits sit at the step of p x 2^24, and random ones
+    with np.errstate(invalid='ignore', over='ignore'):
+        step = np.nan_to_num(np.clip(np.ceil(ps.astype(np.float64) * 2.0 ** 24), 0, (1 << 24) - 1), nan=0.0).astype(np.int64)
+    draws, probs = [], []
+    for d in (-2, -1, 0, 1, 2):
+        u = np.clip(step + d, 0, (1 << 24) - 1).astype(np.uint64)
+        draws.append(((u << np.uint64(8)) | rng.integers(0, 256, len(u)).astype(np.uint64)).astype(np.uint32))
+        probs.append(ps)
+    for _ in range(3):
+        draws.append(rng.integers(0, 1 << 32, len(ps), dtype=np.uint64).astype(np.uint32))
+        probs.append(ps)
+    p_bits = np.ascontiguousarray(np.concatenate(probs).view(np.uint32))
+    r = np.ascontiguousarray(np.concatenate(draws))
+    assert len(p_bits) == len(r) > 400000
+    assert L.par_test_chance_threshold(p_bits.ctypes.data_as(vp), r.ctypes.data_as(vp), len(r)) == 0
+
+
 def test_saturating_maps_compose_like_the_functions_they_stand_for(L):
     """The ordered bed / ICU walk -- and what a sharded population's shards exchange -- rests on one piece of algebra shared by
     the kernels and oracle B (csrc/reina_prims.h): an event acts on a free count as f(x) = max(x + a, m), and two such maps

@@ -1,7 +1,9 @@
 """Where does k_day spend a peak day?  Diagnostic build (-DREINA_ABLATE, REINA_HIP_LIB): the scenario runs normally to
 day 92, then parts of k_day are switched off (timing only -- the state that follows is meaningless) and days 92-98 are
 timed.  python tools/ablate_day.py <bits> [agents]: 1 no target resolution, 2 no normal / exp in the count draw,
-4 no contact sampling at all"""
+4 no contact sampling at all,
+8 no clearing of ACTIVE bits in the plane, 16 no list stores in the state-machine rounds, 32 no store of changed hot words,
+64 no store of onset_days.  ABLATE_START=<day> (default 92), ABLATE_PROF=<lib built with -DREINA_DAY_PROF too>: per-wave cycles"""
 import copy, ctypes, os, sys
 sys.path.insert(0, os.getcwd())
 import bench

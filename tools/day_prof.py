@@ -26,6 +26,16 @@ for day in days:
     k = ctx.engine.profile_read_kernels()
     ctx.engine.profile_enable(0)
     m = ctx.engine.alloc.to_host(ctx.engine.tensors['mirror']).view(np.uint64).astype(np.float64)
-    waves = max(1.0, m[31])
-    print('part %s day %d: k_day %.1f us; per wave: whole loop %.1f kcycles, this part %.1f kcycles in %.1f pieces (%.2f kcycles each)' % (
-        what, day, k['k_day'][0] * 1000.0, m[32] / waves / 1000.0, m[33] / waves / 1000.0, m[34] / waves, m[33] / max(1.0, m[34]) / 1000.0))
+    rows = m[64:].reshape(-1, 4)
+    rows = rows[rows[:, 3] > 0]
+    waves = max(1.0, float(len(rows)))
+    allr = m[64:].reshape(-1, 4)
+    nwg = len(allr) // 16
+    wg = allr[:nwg * 16, 0].reshape(nwg, 16)
+    wg = wg[wg.max(axis=1) > 0]
+    if len(wg):
+        last = wg.max(axis=1) / 1000.0
+        print('   workgroups %d: loop of the LAST wave of a workgroup min %.1f mean %.1f max %.1f kcycles; of the FIRST wave mean %.1f' % (
+            len(wg), last.min(), last.mean(), last.max(), (wg.min(axis=1) / 1000.0).mean()))
+    print('part %s day %d: k_day %.1f us; per wave: whole loop %.1f kcycles (slowest %.1f), this part %.1f kcycles in %.1f pieces (%.2f kcycles each)' % (
+        what, day, k['k_day'][0] * 1000.0, rows[:, 0].sum() / waves / 1000.0, (rows[:, 0].max() if len(rows) else 0.0) / 1000.0, rows[:, 1].sum() / waves / 1000.0, rows[:, 2].sum() / waves, rows[:, 1].sum() / max(1.0, rows[:, 2].sum()) / 1000.0))
