@@ -456,6 +456,7 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     {   // distinct contact rows (entry count, thresholds, meta words): ages of one class of the matrix share a row
         Tables &T = e->h_tables;
         uint32_t n_rows = 0;
+        T.grouped = 1;
         for (uint32_t a = 0; a < A; a++) {
             const uint32_t *thr_a = t->threshold + (size_t)a * REINA_MAX_ENTRIES, *meta_a = t->meta + (size_t)a * REINA_MAX_ENTRIES;
             const size_t used = sizeof(uint32_t) * (size_t)t->count[a];
@@ -473,6 +474,24 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
                     while (idx < cnt - 1 && T.thr[r][idx] <= floor_) idx++;   // thresholds are non-decreasing
                     T.guide[r][b] = (uint8_t)(cnt > 0 ? idx : 0);
                 }
+                // place groups (k_common.inc: Tables::grp)
+                uint32_t *G = T.grp[r];
+                for (int q = 0; q < 5; q++) G[q] = 0xFFFFFFFFu;
+                G[5] = G[6] = G[7] = 0;
+                uint32_t groups = 0, last_place = 0;
+                for (int en = 0; en < cnt; en++) {
+                    const uint32_t place = T.meta[r][en] & 0xFFu;
+                    if (en == 0 || place != last_place) {
+                        if (en > 0 && groups <= 5) G[groups - 1] = T.thr[r][en - 1];
+                        if (groups < 6) G[5] |= (place * 5u) << (5u * groups);
+                        groups++;
+                        last_place = place;
+                    }
+                    if (place >= REINA_NR_PLACES) groups = 99;   // (cannot be packed; never with the places of the model)
+                }
+                for (uint32_t q = groups; q < 6 && groups > 0; q++) G[5] |= (last_place * 5u) << (5u * q);
+                G[6] = groups;
+                if (groups > 6) T.grouped = 0;
                 n_rows++;
             }
             T.row_of_age[a] = (uint8_t)r;
@@ -533,22 +552,22 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     {
         const Tables &T = e->h_tables;
         const uint32_t nr = T.n_rows ? T.n_rows : 1u, nc = T.n_crows ? T.n_crows : 1u;
-        const size_t seg[7][2] = {
+        const size_t seg[8][2] = {
             {offsetof(Tables, thr), sizeof(T.thr[0]) * nr},
             {offsetof(Tables, meta), sizeof(T.meta[0]) * nr},
             {offsetof(Tables, guide), sizeof(T.guide[0]) * nr},
-            {offsetof(Tables, rcount), offsetof(Tables, cthr) - offsetof(Tables, rcount)},   // rcount, row_of_age, n_rows, uniform_meta
+            {offsetof(Tables, grp), sizeof(T.grp[0]) * nr},
+            {offsetof(Tables, rcount), offsetof(Tables, cthr) - offsetof(Tables, rcount)},   // rcount, row_of_age, n_rows, uniform_meta, grouped
             {offsetof(Tables, cthr), sizeof(T.cthr[0]) * nc},
             {offsetof(Tables, cguide), sizeof(T.cguide[0]) * nc},
             {offsetof(Tables, crow_of_age), sizeof(Tables) - offsetof(Tables, crow_of_age)},   // crow_of_age, n_crows, age_shift, age_block
         };
-        segs.n = 7;
-        for (int q = 0; q < 7; q++) {
+        segs.n = 8;
+        for (int q = 0; q < 8; q++) {
             std::memcpy(reinterpret_cast<char *>(&e->stage[slot]->t) + seg[q][0], reinterpret_cast<const char *>(&T) + seg[q][0], seg[q][1]);
             segs.off[q] = (uint32_t)(seg[q][0] / 4);
             segs.words[q] = (uint32_t)(seg[q][1] / 4);
         }
-        segs.off[7] = segs.words[7] = 0;
     }
     // The transfer is a KERNEL that reads the pinned host slot directly (zero-copy): an ordinary
     // dispatch in the day stream.  hipMemcpyAsync of the 98 KB table was measured to block the host
@@ -556,7 +575,7 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
     void *dsrc = nullptr;
     HIP_CHECK(hipHostGetDevicePointer(&dsrc, e->stage[slot], 0));
     static_assert(sizeof(DevParams) % 4 == 0 && sizeof(Tables) % 4 == 0 && offsetof(reina_engine::Stage, t) % 4 == 0 &&
-                  offsetof(Tables, meta) % 4 == 0 && offsetof(Tables, guide) % 4 == 0 && offsetof(Tables, rcount) % 4 == 0 &&
+                  offsetof(Tables, meta) % 4 == 0 && offsetof(Tables, guide) % 4 == 0 && offsetof(Tables, grp) % 4 == 0 && offsetof(Tables, rcount) % 4 == 0 &&
                   offsetof(Tables, cthr) % 4 == 0 && offsetof(Tables, cguide) % 4 == 0 && offsetof(Tables, crow_of_age) % 4 == 0, "word copies");
     const uint32_t *src_w = reinterpret_cast<const uint32_t *>(dsrc);
     hipLaunchKernelGGL(k_upload, dim3(64), dim3(256), 0, s, reinterpret_cast<uint32_t *>(e->d_params), src_w,
