@@ -710,7 +710,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
         const bool par = e->h_params.hosp_parallel != 0;
         if (par) {
             // a large population: the launch's first workgroups are the walkers of a day on which the events' order matters
-            // (one wave per priority bucket: R / 16 workgroups; they leave at once on any other day), the others install.
+            // (one wave per priority bucket: R / 16 workgroups; on any other day they install too), the others install.
             // One workgroup of 1024 threads per CU: all of them resident together, so the walk runs beside the installs.
             const uint32_t n_walk = (e->h_params.hosp_ranges + 15u) / 16u;
             int rest = (int)e->n_cus - (int)n_walk;
