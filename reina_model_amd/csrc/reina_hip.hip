@@ -269,6 +269,10 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 1)
             e->n_cus = (uint32_t)cus;
+        if (const char *w = std::getenv("REINA_WALK_DIV")) {
+            const int v = std::atoi(w);
+            if (v >= 16 && v <= 1024) e->walk_div = (uint32_t)v;
+        }
         if (const char *w = std::getenv("REINA_IMPORT_WGS")) {
             const int v = std::atoi(w);
             if (v >= 1 && v <= 16) e->import_wgs = (uint32_t)v;
@@ -712,7 +716,7 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
             // a large population: the launch's first workgroups are the walkers of a day on which the events' order matters
             // (one wave per priority bucket: R / 16 workgroups; on any other day they install too), the others install.
             // One workgroup of 1024 threads per CU: all of them resident together, so the walk runs beside the installs.
-            const uint32_t n_walk = (e->h_params.hosp_ranges + 15u) / 16u;
+            const uint32_t n_walk = (e->h_params.hosp_ranges + e->walk_div - 1u) / e->walk_div;
             int rest = (int)e->n_cus - (int)n_walk;
             if (K > 1) rest = (int)(e->n_cus / K) - (int)n_walk;
             if (rest > ig) rest = ig;
