@@ -269,6 +269,11 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 1)
             e->n_cus = (uint32_t)cus;
+        if (const char *w = std::getenv("REINA_NO_PLACE_GROUPS")) e->no_place_groups = std::atoi(w) != 0;
+        if (const char *w = std::getenv("REINA_LDS_ROWS_CAP")) {
+            const int v = std::atoi(w);
+            if (v >= 1) e->lds_rows_cap = (uint32_t)v;
+        }
         if (const char *w = std::getenv("REINA_WALK_DIV")) {
             const int v = std::atoi(w);
             if (v >= 16 && v <= 1024) e->walk_div = (uint32_t)v;
@@ -501,6 +506,7 @@ int reina_upload_contact_tables(reina_engine_t *e, const reina_contact_tables_t 
             T.row_of_age[a] = (uint8_t)r;
         }
         T.n_rows = n_rows;
+        if (e->no_place_groups) T.grouped = 0;
         // contact-count thresholds: one row per distinct nr_contacts_by_age value
         uint32_t n_crows = 0;
         float crow_value[REINA_MAX_AGES];
@@ -654,8 +660,10 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
     }
     uint32_t lds_rows = K > 1 ? e->group_lds_rows : e->h_tables.n_rows;   // (a member stages min(its own rows, lds_rows))
     if (lds_rows > REINA_LDS_ROWS) lds_rows = REINA_LDS_ROWS;
+    if (e->lds_rows_cap && lds_rows > e->lds_rows_cap) lds_rows = e->lds_rows_cap;
     uint32_t lds_crows = K > 1 ? e->group_lds_crows : e->h_tables.n_crows;
     if (lds_crows > REINA_LDS_CROWS) lds_crows = REINA_LDS_CROWS;
+    if (e->lds_rows_cap && lds_crows > e->lds_rows_cap) lds_crows = e->lds_rows_cap;
     {
         const int helpers = weekly_own == OPEN_WEEKLY_IN_STREAM ? 0 : weekly_own > 0 ? weekly_own : -weekly_own;
         const int g0 = 1 + (helpers > 1 ? helpers : 1), g = g0 + tg;

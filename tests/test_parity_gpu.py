@@ -221,6 +221,29 @@ def test_the_alternative_launch_shapes_of_the_opening_give_the_same_days(env, mo
         _run_and_compare(vv, ages, 5, 135, chunk=45)
 
 
+@pytest.mark.parametrize('env', [{'REINA_NO_PLACE_GROUPS': '1'}, {'REINA_LDS_ROWS_CAP': '3'}, {'REINA_NO_PLACE_GROUPS': '1', 'REINA_LDS_ROWS_CAP': '3'}])
+def test_the_contact_tables_fallbacks_give_the_same_days(env, monkeypatch):
+    """k_day finds a contact's place from its row's place groups (five comparisons) and leaves the table entry to the contacts
+    that pass the thinning -- when every row's entries are sorted by place (the reference's always are; a caller of the C ABI
+    may pass any order) and every distinct row fits the LDS image.  Otherwise the full entry search serves every contact, and a
+    row beyond the image is read through L2.  Both fallbacks forced here (REINA_NO_PLACE_GROUPS; REINA_LDS_ROWS_CAP = 3 of the
+    default scenario's 16 contact rows and count rows), alone and together, on scenarios with mobility windows that split the
+    rows, against oracle B: the same days bit for bit."""
+    for k, x in env.items():
+        monkeypatch.setenv(k, x)
+    _, meta = load_run('mini_kitchen_s3')
+    _run_and_compare(variables_for(meta), np.asarray(meta['age_counts']), meta['seed'], meta['days'], interventions=meta['interventions'])
+    for case in (3, 7):
+        rng = np.random.default_rng(1000 + case)
+        vv, ages, days, ivs, ipc = _random_scenario(rng)
+        _run_and_compare(vv, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    monkeypatch.setenv('REINA_DAY_MODE', 'sparse')
+    _run_and_compare(v, datasets.scaled_population(200000), 5, 160, chunk=80)
+    monkeypatch.setenv('REINA_DAY_MODE', 'dense')
+    _run_and_compare(v, datasets.scaled_population(200000), 6, 160, chunk=80)
+
+
 def test_sparse_dense_and_mixed_years_of_the_hus_population_are_identical(monkeypatch):
     """BASELINE configs[1] (1 685 983 agents x 365 days): the year as run by default (sparse days below 2.5 % active agents,
     dense days above: both forms occur), all days dense and all days sparse give the identical history and final state;
