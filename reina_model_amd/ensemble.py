@@ -54,8 +54,15 @@ def run_group_plan(contexts, plan, record_history=True, member_plans=None):
     out = None
     if record_history:
         out = a.to_host(hist).reshape(K, days, _eng.COUNTER_WORDS)
-    for c in contexts:
-        c._raise_on_problem(c.engine.read_counters())
+    torch = getattr(a, 'torch', None)
+    if torch is not None:
+        # the members' final counter blocks (the problem word among them) in one copy instead of one per member (4 ms for 128)
+        finals = a.to_host(torch.stack([c.engine.tensors['counters'] for c in contexts]))
+        for m, c in enumerate(contexts):
+            c._raise_on_problem(np.asarray(finals[m]))
+    else:
+        for c in contexts:
+            c._raise_on_problem(c.engine.read_counters())
     group.close()
     return out
 
