@@ -668,6 +668,21 @@ def test_large_tracing_queues(total, days):
     assert c['all_detected'].sum() > 50_000   # >> 1024 queue entries on the busy days
 
 
+def test_mass_vaccination_programmes_against_oracle_b():
+    """HealthcareSystem.vaccinate_people (main.pyx:560-583) at a scale the other scenarios do not reach: k_vaccinate looks at
+    16 x 1024 agents below a programme's cursor per step, so a day's number above 16 384 takes several steps, ends in the
+    middle of one, and crosses age boundaries inside a wave -- 400 000 agents, two programmes on overlapping age ranges
+    (23 000 and 9000 a day), a third that starts later and runs out of eligible agents, detections and deaths in between
+    (agents skipped once stay ineligible): every day's counters incl. `vaccinated` by age, every agent's vaccination day."""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ivs = [['import-infections', '2020-02-19', 400], ['test-all-with-symptoms', '2020-02-22'],
+           ['vaccinate', '2020-02-24', 161000, 40, 100], ['vaccinate', '2020-02-27', 63000, 60, 80],
+           ['vaccinate', '2020-03-10', 350000, 12, 39], ['vaccinate', '2020-03-20', 7000, 40, 100]]
+    gpu, cpu = _run_and_compare(v, datasets.scaled_population(400000), 21, 60, interventions=ivs, chunk=20)
+    c = gpu.per_age_counters()
+    assert c['vaccinated'].sum() > 300000
+
+
 def test_three_variants():
     """wild type + two variants with their own multipliers and durations, imported by date and through
     the weekly shares (one 'variant_<name>' share per variant, common/interventions.py:300-323)"""
