@@ -1218,6 +1218,38 @@ void par_test_sat(int a1, int m1, int a2, int m2, int x, int *out) {
     rp_sat_unpack(rp_sat_pack(f, g), &fb, &fc);
     out[3] = fb.a; out[4] = fb.m; out[5] = fc.a; out[6] = fc.m;
 }
+/* k_day's place groups against the entry search they stand for.  The HIP library derives, per distinct contact row, the thresholds
+ * at which the PLACE of the selected entry changes (reina_hip.hip: reina_upload_contact_tables -> Tables::grp; a row's entries are
+ * sorted by place) and k_day finds a contact's place from five comparisons; oracle B and the contacts that can transmit search the
+ * entry itself.  Restated here: the derivation and both look-ups for one row (thr non-decreasing, place = meta & 0xFF) and n draws;
+ * returns the number of draws on which they disagree, -1 when the row has more than six place groups (the library then keeps the
+ * full search). */
+int par_test_place_groups(const uint32_t *thr, const uint32_t *meta, int cnt, const uint32_t *r0, int n) {
+    uint32_t G[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0};
+    uint32_t groups = 0, last_place = 0;
+    for (int e = 0; e < cnt; e++) {
+        const uint32_t place = meta[e] & 0xFFu;
+        if (e == 0 || place != last_place) {
+            if (e > 0 && groups <= 5) G[groups - 1] = thr[e - 1];
+            if (groups < 6) G[5] |= (place * 5u) << (5u * groups);
+            groups++;
+            last_place = place;
+        }
+    }
+    if (groups > 6) return -1;
+    for (uint32_t q = groups; q < 6 && groups > 0; q++) G[5] |= (last_place * 5u) << (5u * q);
+    int bad = 0;
+    for (int k = 0; k < n; k++) {
+        int l2 = 0;
+        while (l2 < cnt - 1 && r0[k] >= thr[l2]) l2++;   /* first entry with r0 < threshold; none: the last one */
+        const uint32_t place_entry = cnt > 0 ? (meta[l2] & 0xFFu) : 0u;
+        uint32_t g = 0;
+        for (int q = 0; q < 5; q++) g += r0[k] >= G[q];
+        const uint32_t place_group = ((G[5] >> (5u * g)) & 31u) / 5u;
+        bad += cnt > 0 && place_entry != place_group;
+    }
+    return bad;
+}
 /* rp_chance against its integer form (csrc/reina_prims.h: rp_chance_threshold; k_day tests a source's thinning bound that
  * way): n (probability bits, draw) pairs -> the number of pairs on which the two disagree */
 int par_test_chance_threshold(const uint32_t *p_bits, const uint32_t *r, int n) {

@@ -192,6 +192,44 @@ def test_a_chance_is_one_integer_comparison(L):
     assert L.par_test_chance_threshold(p_bits.ctypes.data_as(vp), r.ctypes.data_as(vp), len(r)) == 0
 
 
+def test_a_contacts_place_from_its_rows_place_groups(L):
+    """k_day takes the PLACE of a contact from at most five comparisons against the thresholds at which the place of the selected
+    table entry changes (Tables::grp, derived when the tables are uploaded) and leaves the entry search to the contacts that can
+    transmit; oracle B searches the entry for every contact.  The derivation and both look-ups, restated in the oracle library, on
+    random rows -- 1 to 96 entries sorted by place, places without entries, entries of probability zero (repeated thresholds) at
+    the start, in the middle and at the end, a row that saturates early (trailing 0xFFFFFFFF) -- and on the draws that matter:
+    every threshold, its neighbours, 0, 0xFFFFFFFF, random ones.  (The GPU suite holds the library's own derivation against oracle
+    B on real tables; a draw of exactly 0xFFFFFFFF never occurs there.)"""
+    L.par_test_place_groups.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int]
+    L.par_test_place_groups.restype = ctypes.c_int
+    rng = np.random.default_rng(23)
+    for case in range(400):
+        cnt = int(rng.integers(1, 97))
+        nplaces = int(rng.integers(1, 7))
+        places = np.sort(rng.choice(6, size=nplaces, replace=False))
+        place = np.sort(rng.choice(places, size=cnt))                    # sorted by place; some of the chosen places may get no entry
+        p = rng.random(cnt)
+        p[rng.random(cnt) < (0.0, 0.3, 0.7)[case % 3]] = 0.0               # entries of probability zero
+        if case % 5 == 0:
+            p[int(rng.integers(0, cnt)):] = 0.0                           # the row saturates early
+        if p.sum() == 0.0:
+            p[int(rng.integers(0, cnt))] = 1.0
+        cum = np.cumsum(p) / p.sum()
+        thr = np.clip(np.floor(cum * 4294967296.0), 0, 4294967295.0).astype(np.uint64).astype(np.uint32)
+        meta = (place.astype(np.uint32) | (rng.integers(0, 100, cnt).astype(np.uint32) << 8))
+        edges = thr.astype(np.int64)
+        draws = np.concatenate([edges, edges - 1, edges + 1, [0, 1, 0xFFFFFFFE, 0xFFFFFFFF], rng.integers(0, 1 << 32, 300)])
+        draws = np.clip(draws, 0, 0xFFFFFFFF).astype(np.uint32)
+        thr = np.ascontiguousarray(thr); meta = np.ascontiguousarray(meta); draws = np.ascontiguousarray(draws)
+        bad = L.par_test_place_groups(thr.ctypes.data_as(vp), meta.ctypes.data_as(vp), cnt, draws.ctypes.data_as(vp), len(draws))
+        assert bad == 0, (case, cnt, bad)
+    # a row whose entries are NOT sorted by place has more than six groups: the library keeps the full search for such tables
+    place = np.tile(np.arange(6, dtype=np.uint32), 4)
+    thr = np.ascontiguousarray((np.arange(1, 25, dtype=np.uint64) * (1 << 27)).astype(np.uint32))
+    draws = np.ascontiguousarray(np.array([5], dtype=np.uint32))
+    assert L.par_test_place_groups(thr.ctypes.data_as(vp), np.ascontiguousarray(place).ctypes.data_as(vp), 24, draws.ctypes.data_as(vp), 1) == -1
+
+
 def test_saturating_maps_compose_like_the_functions_they_stand_for(L):
     """The ordered bed / ICU walk -- and what a sharded population's shards exchange -- rests on one piece of algebra shared by
     the kernels and oracle B (csrc/reina_prims.h): an event acts on a free count as f(x) = max(x + a, m), and two such maps
