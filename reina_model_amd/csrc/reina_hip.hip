@@ -269,6 +269,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 1)
             e->n_cus = (uint32_t)cus;
+        if (const char *w = std::getenv("REINA_VACC_ONE_WG")) e->vacc_one_wg = std::atoi(w) != 0;   // (the single-workgroup vaccination pass at every size: the tests compare)
         if (const char *w = std::getenv("REINA_NO_PLACE_GROUPS")) e->no_place_groups = std::atoi(w) != 0;
         if (const char *w = std::getenv("REINA_LDS_ROWS_CAP")) {
             const int v = std::atoi(w);
@@ -682,7 +683,17 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         }
         // a vaccination programme: its pass over the agents comes after the test queue and before the stream
         // (HealthcareSystem.iterate, main.pyx:514-558)
-        if (dp.n_vaccinations) LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(1, K), dim3(PRO_THREADS), 0, s, dp);
+        if (dp.n_vaccinations) {
+            // ONE programme whose number of the day exceeds a step of 16 x 1024 agents, a single engine: a chain of workgroups, one
+            // step each, with room for a third more agents than the number (k_open.inc: pro_vaccinate_chain); otherwise one workgroup
+            uint32_t vg = 1;
+            if (K == 1 && dp.n_vaccinations == 1 && dp.vaccinations[0].nr > VACC_CHUNKS * PRO_THREADS && e->cfg.max_work_items >= 4096 && !e->vacc_one_wg) {
+                vg = (dp.vaccinations[0].nr + dp.vaccinations[0].nr / 3u) / (VACC_CHUNKS * PRO_THREADS) + 1u;
+                if (vg > e->n_cus) vg = e->n_cus;
+                if (vg > 256u) vg = 256u;
+            }
+            LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(vg, K), dim3(PRO_THREADS), 0, s, dp);
+        }
         LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks + stream_imports, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows,
                    e->day_sparse_below, e->day_flags, stream_imports);
     }

@@ -683,6 +683,23 @@ def test_mass_vaccination_programmes_against_oracle_b():
     assert c['vaccinated'].sum() > 300000
 
 
+@pytest.mark.parametrize('one_wg', [False, True])
+def test_one_vaccination_programme_by_a_chain_of_workgroups(one_wg, monkeypatch):
+    """A day with ONE programme whose number exceeds a step of 16 384 agents is shared by a chain of workgroups, one step each,
+    that pass on the number of eligible agents in front of them and, once reached, the final cursor (k_open.inc:
+    pro_vaccinate_chain); the last one goes on alone when the steps did not hold enough eligible agents.  2 000 000 agents:
+    60 000 a day from day 6 (five workgroups), over ages 30-100 until the range is used up and the cursor stops at its lower
+    end; then 250 000 a day over ages 5-29, of whom there are fewer than a day's number at the end; an epidemic with detections
+    runs beside it, so whole stretches of agents are ineligible.  Against oracle B, and with the chain switched off
+    (REINA_VACC_ONE_WG) the same."""
+    if one_wg:
+        monkeypatch.setenv('REINA_VACC_ONE_WG', '1')
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ivs = [['import-infections', '2020-02-19', 3000], ['test-all-with-symptoms', '2020-02-20'],
+           ['vaccinate', '2020-02-24', 420000, 30, 100], ['vaccinate', '2020-03-20', 0, 30, 100], ['vaccinate', '2020-03-20', 1750000, 5, 29]]
+    _run_and_compare(v, datasets.scaled_population(2000000), 4, 40, interventions=ivs, chunk=20)
+
+
 def test_three_variants():
     """wild type + two variants with their own multipliers and durations, imported by date and through
     the weekly shares (one 'variant_<name>' share per variant, common/interventions.py:300-323)"""
