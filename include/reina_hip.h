@@ -72,6 +72,30 @@ extern "C" {
 #define REINA_PROBLEM_HOSPITAL_OVERFLOW 103
 #define REINA_PROBLEM_DAYS_OVERFLOW 104
 #define REINA_PROBLEM_SYNC_TIMEOUT 105   /* a workgroup gave up waiting (2^22 polls, seconds) for the day's opening bookkeeping */
+#define REINA_PROBLEM_EXCHANGE_OVERFLOW 106   /* exact attribution: more records for one peer shard than an exchange segment holds (reina_config_t.xchg_cap) */
+#define REINA_PROBLEM_INFECTEE_POOL_OVERFLOW 107   /* exact attribution: more infectees beyond the inline slots than reina_config_t.pool_cap */
+
+/* EXACT CROSS-SHARD ATTRIBUTION (the reference records the TRUE infector and appends to the infector's
+ * infectee array at infection time, main.pyx:219-233, and contact tracing walks exactly those links, :495-512).
+ * With reina_config_t.exact_attribution every link field of a sharded population -- reina_cold_t.infector, the inline
+ * infectee slots, the overflow list -- holds a GLOBAL id (shard, index), and the shards exchange 8-byte records through
+ * fixed-capacity all-to-all segments (buffers.xsend / xrecv) instead of the pressure counts:
+ *   contact records   (mid-day, with the all-reduce): a cross-shard contact that passed did_infect's whole test at the source
+ *                     (the source knows the target's age: every shard's age_start table is global knowledge) -> the target's
+ *                     shard, which claims the target with the source's own key;
+ *   feedback records  (after the day's last launch): (source, infectee) of every cross-shard infection -> the source's
+ *                     shard, so that its infection count and infectee list are true before the next morning;
+ *   tracing requests  (contact-tracing days, one exchange per level): (candidate, tracer) -> the candidate's shard, which
+ *                     rolls (the roll is keyed by candidate and tracer), queues, and expands level 1.
+ * A global id is non-negative as an int32 (-1 stays "none"): 4 bits of shard above 27 bits of index, so an engine instance
+ * holds fewer than 2^27 agents in this mode. */
+#define REINA_GID_SHIFT 27
+#define REINA_GID_INDEX_MASK ((1u << REINA_GID_SHIFT) - 1u)
+#define REINA_GID(shard, index) ((int32_t)(((uint32_t)(shard) << REINA_GID_SHIFT) | (uint32_t)(index)))
+/* an exchange buffer: n_shards segments of (xchg_cap + 1) 64-bit words; segment d of xsend is bound for shard d, segment s
+ * of xrecv came from shard s; word 0 of a segment = its record count (may exceed xchg_cap after an overflow: readers clamp),
+ * then the records: [gid : 31 << 32][flags : 5 << 27][index at the receiving shard : 27] (csrc/reina_prims.h: rp_xrec) */
+#define REINA_XCHG_WORDS(n_shards, xchg_cap) ((size_t)(n_shards) * ((size_t)(xchg_cap) + 1u))
 
 /* per-age counter arrays, Population stats main.pyx:1335-1341 */
 enum {
@@ -119,6 +143,7 @@ enum {
     REINA_L_ACTIVE = 24,                                /* [2] agents the daily stream found something to do for (infected, or removed and not
                                                            yet counted into R), word [day & 1]: yesterday's count tells k_day whether to stream
                                                            every hot word or only buffers.active_bits (sparse days) */
+    REINA_L_POOL = 26,                                  /* exact attribution: nodes of buffers.infectee_pool handed out so far */
     REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_DET_SIDE = 48,                              /* [REINA_MAX_AGES] the day's detections by age from the test queue (the day's opening
                                                            launch), folded into the counters by the day's last launch */
@@ -181,6 +206,13 @@ typedef struct {
                                  shards exchange per-bucket maps of the day's bed / ICU events */
     int32_t age_start[REINA_MAX_AGES + 1]; /* first agent index of each age; [A] = n_agents
                                               (Population.age_start, main.pyx:1332,1442) */
+    uint32_t exact_attribution; /* sharded populations: 1 = exact cross-shard attribution (above), 0 = mirror attribution
+                                   (stand-in infectors, one all-reduce per day; reina_model_amd/sharding.py) */
+    uint32_t xchg_cap;          /* exact attribution: records per peer segment of buffers.xsend / xrecv */
+    uint32_t pool_cap;          /* exact attribution: nodes of buffers.infectee_pool */
+    uint32_t reserved_;
+    const int32_t *shard_age_start; /* exact attribution: host array [n_shards][REINA_MAX_AGES + 1], every shard's age_start
+                                       (read by reina_create only) */
 } reina_config_t;
 
 /* Disease parameters, all float32 like the reference's `cdef float` fields (main.pyx:787-806).
@@ -242,8 +274,10 @@ typedef struct {
     int32_t n_infected;       /* Person.other_people_infected */
     float onset_days;         /* Person.days_from_onset_to_removed */
     int32_t vacc_day;         /* Person.day_of_vaccination, -1 = never */
-    int32_t first_infectee;   /* infectees beyond the REINA_INLINE_INFECTEES inline slots: head of a linked list, -1 = empty */
-    int32_t next_sibling;     /* ... and its link: next such infectee of the same infector, -1 = end */
+    int32_t first_infectee;   /* infectees beyond the REINA_INLINE_INFECTEES inline slots: head of a linked list, -1 = empty
+                                 (exact attribution: a node of buffers.infectee_pool) */
+    int32_t next_sibling;     /* ... and its link: next such infectee of the same infector, -1 = end (exact attribution: unused,
+                                 the links are in the pool) */
 } reina_cold_t;
 /* Person.infectees (main.pyx:128,231: 64 ids per person, kept while contact tracing is on): the first
  * REINA_INLINE_INFECTEES of an agent's infectees sit side by side in buffers.infectees (slot = their rank among the
@@ -293,6 +327,11 @@ typedef struct {
                                  (person_expose's test, main.pyx:239).  A contact that can transmit looks its target up here --
                                  a table of N / 8 bytes that stays in the 256 MB Infinity Cache -- instead of gathering the
                                  target's hot word from HBM */
+    uint64_t *xsend;          /* [REINA_XCHG_WORDS(n_shards, xchg_cap)] exact attribution: records bound for the other shards */
+    uint64_t *xrecv;          /* [REINA_XCHG_WORDS(n_shards, xchg_cap)] ... and what the all-to-all brought from them */
+    uint32_t *infectee_pool;  /* [2 * pool_cap] exact attribution: (infectee gid, next node or -1) of the infectees beyond an
+                                 agent's inline slots -- an infectee may live on another shard, so the list cannot be threaded
+                                 through the infectees' own records.  (Without exact attribution: any non-null pointers.) */
 } reina_buffers_t;
 /* words of a per-agent bit plane: whole 512-agent tiles of 16 words (k_day's wave tiles), and one spare tile */
 #define REINA_BITS_WORDS(n_agents) ((((size_t)(n_agents) + 511u) / 512u + 1u) * 16u)
@@ -374,6 +413,25 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream);
 typedef int (*reina_allreduce_fn)(const void *sendbuff, void *recvbuff, size_t count, int datatype, int op,
                                   void *comm, void *stream);
 int reina_set_collective(reina_engine_t *e, reina_allreduce_fn allreduce, void *comm);
+/* exact attribution: `alltoall` has the signature of RCCL's ncclAllToAll (sendbuff, recvbuff, count per peer, datatype, comm,
+ * stream) and is called as alltoall(xsend, xrecv, xchg_cap + 1, 4 = ncclInt64, comm, stream) on the day stream wherever
+ * reina_step_phase asks for REINA_X_ALLTOALL. */
+typedef int (*reina_alltoall_fn)(const void *sendbuff, void *recvbuff, size_t count, int datatype, void *comm, void *stream);
+int reina_set_alltoall(reina_engine_t *e, reina_alltoall_fn alltoall, void *comm);
+/* One day as the phases between which a sharded population exchanges: reina_step_day == the phases in order with the
+ * collectives they return queued in between.  Returns < 0 on error, else the collectives the caller must run before the next
+ * phase: REINA_X_ALLREDUCE = sum buffers.pressure over the shards (REINA_EXCHANGE_WORDS int32), REINA_X_ALLTOALL = segment d of
+ * every shard's buffers.xsend -> segment (sender's rank) of shard d's buffers.xrecv.
+ *   REINA_PH_OPEN      the day's opening: snapshot, imports, test queue, level-0 tracing   -> ALLTOALL (exact, tracing days)
+ *   REINA_PH_TRACE     exact, tracing days: the received level-0 requests, level-1 tracing -> ALLTOALL (exact, tracing days)
+ *   REINA_PH_MAIN      (the received level-1 requests,) vaccination, the stream + contacts  -> ALLREDUCE (sharded) | ALLTOALL (exact)
+ *   REINA_PH_END       cross-shard contacts claim, bed / ICU events, installs                -> ALLTOALL (exact)
+ *   REINA_PH_FEEDBACK  exact: the sources of cross-shard infections take their infectees
+ * reina_step_day_begin == OPEN + TRACE + MAIN and reina_step_day_end == END + FEEDBACK for a population WITHOUT exact attribution. */
+enum { REINA_PH_OPEN = 0, REINA_PH_TRACE, REINA_PH_MAIN, REINA_PH_END, REINA_PH_FEEDBACK, REINA_PH_NR };
+#define REINA_X_ALLREDUCE 1
+#define REINA_X_ALLTOALL 2
+int reina_step_phase(reina_engine_t *e, const reina_day_t *day, int phase, void *stream);
 /* the same day in two halves for a sharded population: `begin` runs everything up to and including
  * contact sampling and leaves this shard's outgoing pressure (and its free capacity / demand words) in
  * buffers.pressure; the caller sums `pressure` over all shards (ncclAllReduce / torch.distributed.all_reduce,
@@ -420,7 +478,7 @@ int reina_read_history(reina_engine_t *e, const int32_t *history_dev, uint32_t n
  * over all kinds. */
 enum {
     REINA_PK_OPEN = 0, REINA_PK_TRACE1, REINA_PK_VACCINATE, REINA_PK_DAY, REINA_PK_HOSPITAL, REINA_PK_HOSP_SORT,
-    REINA_PK_HOSP_WALK, REINA_PK_REMOTE, REINA_PK_INSTALL, REINA_PK_NR
+    REINA_PK_HOSP_WALK, REINA_PK_REMOTE, REINA_PK_INSTALL, REINA_PK_XCHG /* exact attribution: the kernels that take in exchanged records */, REINA_PK_NR
 };
 int reina_profile_enable(reina_engine_t *e, int enable);
 int reina_profile_read_kernels(reina_engine_t *e, double *ms_total, uint64_t *launches);

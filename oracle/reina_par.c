@@ -43,6 +43,13 @@ typedef struct {
     uint32_t hosp_ranges, hosp_range_bits;              /* priority buckets of the day's bed / ICU events (sharded: exchanged maps) */
     reina_allreduce_fn coll_fn;
     void *coll_comm;
+    /* exact cross-shard attribution (include/reina_hip.h): global ids in every link field, 8-byte records exchanged */
+    int exact;
+    uint32_t gid_base, gid_mask;   /* reina_prims.h: rp_gid_is_local */
+    int32_t shard_age_start[REINA_MAX_SHARDS][REINA_MAX_AGES + 1];   /* every shard's age_start: a source works out its target's age */
+    uint32_t shard_k0[REINA_MAX_SHARDS], shard_k1[REINA_MAX_SHARDS];  /* every shard's Philox key: a target recomputes its source's priority */
+    reina_alltoall_fn a2a_fn;
+    void *a2a_comm;
 } Par;
 
 #define CNT(e, c, age) ((e)->buf.counters[(c) * REINA_MAX_AGES + (age)])
@@ -68,7 +75,29 @@ static int age_of(const Par *e, uint32_t i) {
     return lo;
 }
 
-int par_abi_version(void) { return 4; }
+int par_abi_version(void) { return 5; }
+
+/* ---------------------------------------------------------------- exact attribution: ids and exchange segments */
+static int32_t gid_of(const Par *e, uint32_t i) { return (int32_t)(e->gid_base | i); }
+static int gid_local(const Par *e, int32_t g) { return (int)rp_gid_is_local((uint32_t)g, e->gid_base, e->gid_mask); }
+static uint32_t gid_index(const Par *e, int32_t g) { return (uint32_t)g & e->gid_mask; }
+static uint64_t *xseg(const Par *e, uint64_t *buf, uint32_t shard) { return buf + (size_t)shard * ((size_t)e->cfg.xchg_cap + 1u); }
+static void xsend_push(Par *e, uint32_t dest, uint64_t rec) {
+    uint64_t *seg = xseg(e, e->buf.xsend, dest);
+    if (seg[0] >= e->cfg.xchg_cap) {
+        set_problem(e, REINA_PROBLEM_EXCHANGE_OVERFLOW);
+        return;
+    }
+    seg[1 + seg[0]++] = rec;
+}
+static void xsend_reset(Par *e) {
+    for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) xseg(e, e->buf.xsend, sh)[0] = 0;
+}
+/* records shard `sh` sent to this one in the last exchange */
+static uint32_t xrecv_count(const Par *e, uint32_t sh) {
+    const uint64_t n = xseg(e, e->buf.xrecv, sh)[0];
+    return n > e->cfg.xchg_cap ? e->cfg.xchg_cap : (uint32_t)n;
+}
 
 /* Context.sample: the shared host-side sampler (utility, not part of the day step) */
 int par_sample(const reina_disease_t *disease, uint64_t seed, int what, int age, int severity,
@@ -107,6 +136,23 @@ int par_create(const reina_config_t *cfg, const reina_disease_t *disease, Par **
             if (disease->p_susceptibility[v][a] > m) m = disease->p_susceptibility[v][a];
         e->psus_max[v] = m;
     }
+    e->exact = cfg->exact_attribution && e->cfg.n_shards > 1;
+    e->gid_mask = 0xFFFFFFFFu;
+    if (e->exact) {
+        if (!cfg->shard_age_start || !cfg->xchg_cap || !cfg->pool_cap || cfg->n_agents > RP_GID_INDEX_MASK) {
+            free(e);
+            return REINA_E_INVALID;
+        }
+        e->gid_base = e->cfg.shard_rank << RP_GID_SHIFT;
+        e->gid_mask = RP_GID_INDEX_MASK;
+        memcpy(e->shard_age_start, cfg->shard_age_start, sizeof(int32_t) * (size_t)e->cfg.n_shards * (REINA_MAX_AGES + 1));
+        for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+            const uint64_t ss = rp_shard_seed(cfg->seed, sh);
+            e->shard_k0[sh] = (uint32_t)ss;
+            e->shard_k1[sh] = (uint32_t)(ss >> 32);
+        }
+    }
+    e->cfg.shard_age_start = NULL;   /* (the caller's array is not kept) */
     *out = e;
     return 0;
 }
@@ -145,6 +191,7 @@ int par_init_state(Par *e, int32_t beds, int32_t icu, void *stream) {
     }
     memset(e->buf.counters, 0, sizeof(int32_t) * REINA_COUNTER_WORDS);
     memset(e->buf.control, 0, sizeof(int32_t) * REINA_L_NR);
+    if (e->exact) xsend_reset(e);
     for (uint32_t a = 0; a < e->cfg.nr_ages; a++)
         CNT(e, REINA_C_SUSCEPTIBLE, a) = e->cfg.age_start[a + 1] - e->cfg.age_start[a];
     SC(e, REINA_S_AVAILABLE_BEDS) = SC(e, REINA_S_BEDS) = beds;
@@ -207,6 +254,34 @@ static uint32_t clamp_days(Par *e, int d) {
     return (uint32_t)d;
 }
 
+/* the source's half of person_infect (main.pyx:219-233): other_people_infected++, and the infectee appended to its list */
+static void source_gains_infectee(Par *e, uint32_t s, int32_t infectee, uint32_t src_has_list) {
+    int old = e->buf.cold[s].n_infected++;
+    /* the source keeps an infectee list: its START-of-day word, carried in the candidate record
+     * (person_expose_others runs before the source's own transition of the day, main.pyx:404-414) */
+    if (!src_has_list) return;
+    /* Person.infectees (main.pyx:128,231): the first REINA_INLINE_INFECTEES by rank in the source's inline block,
+     * the others on its linked list -- threaded through the infectees' own records, or, when infectees may live on
+     * another shard (exact attribution), through nodes of the pool */
+    if (old >= 64) {
+        set_problem(e, 1 /* TOO_MANY_INFECTEES */);
+    } else if (old < REINA_INLINE_INFECTEES) {
+        e->buf.infectees[(size_t)s * REINA_INLINE_INFECTEES + (uint32_t)old] = infectee;
+    } else if (e->exact) {
+        if ((uint32_t)CTL(e, REINA_L_POOL) >= e->cfg.pool_cap) {
+            set_problem(e, REINA_PROBLEM_INFECTEE_POOL_OVERFLOW);
+            return;
+        }
+        const uint32_t node = (uint32_t)CTL(e, REINA_L_POOL)++;
+        e->buf.infectee_pool[2u * node] = (uint32_t)infectee;
+        e->buf.infectee_pool[2u * node + 1u] = (uint32_t)e->buf.cold[s].first_infectee;
+        e->buf.cold[s].first_infectee = (int32_t)node;
+    } else {
+        e->buf.cold[infectee].next_sibling = e->buf.cold[s].first_infectee;
+        e->buf.cold[s].first_infectee = infectee;
+    }
+}
+
 /* person_infect (main.pyx:209-235) + Population.infect (:1576-1582) */
 static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant, int32_t src,
                               int fresh, uint32_t testing_mode, uint32_t src_has_list) {
@@ -228,22 +303,13 @@ static void install_infection(Par *e, uint32_t t, uint32_t day, uint32_t variant
                   RH_INFECTED_ON((fresh && day == RP_INIT_DAY) ? day + 1u : day);
     e->buf.hot[t] = nw;
     if (src >= 0) {
+        /* `src` is a global id when the population keeps them (exact attribution): the source's own shard counts the
+         * infection and keeps the infectee list -- this one at once, another one when the day's feedback records arrive */
         e->buf.cold[t].infector = src;
-        int old = e->buf.cold[src].n_infected++;
-        /* the source keeps an infectee list: its START-of-day word, carried in the candidate record
-         * (person_expose_others runs before the source's own transition of the day, main.pyx:404-414) */
-        if (src_has_list) {
-            /* Person.infectees (main.pyx:128,231): the first REINA_INLINE_INFECTEES by rank in the source's inline block,
-             * the others on its linked list */
-            if (old >= 64) {
-                set_problem(e, 1 /* TOO_MANY_INFECTEES */);
-            } else if (old < REINA_INLINE_INFECTEES) {
-                e->buf.infectees[(size_t)src * REINA_INLINE_INFECTEES + (uint32_t)old] = (int32_t)t;
-            } else {
-                e->buf.cold[t].next_sibling = e->buf.cold[src].first_infectee;
-                e->buf.cold[src].first_infectee = (int32_t)t;
-            }
-        }
+        if (gid_local(e, src))
+            source_gains_infectee(e, gid_index(e, src), gid_of(e, t), src_has_list);
+        else
+            xsend_push(e, rp_gid_shard((uint32_t)src), rp_xrec(gid_index(e, src), src_has_list << 2, (uint32_t)gid_of(e, t)));
     }
     CNT(e, REINA_C_SUSCEPTIBLE, age) -= 1;
     CNT(e, REINA_C_INFECTED, age) += 1;
@@ -355,8 +421,41 @@ static int try_queue(Par *e, uint32_t cand, uint32_t tracer, const reina_day_t *
     return 1;
 }
 
-/* HealthcareSystem.iterate (main.pyx:514-558) + perform_contact_tracing (:495-512) */
-static void run_testing(Par *e, const reina_day_t *dp) {
+/* perform_contact_tracing (main.pyx:495-512) for one candidate of tracer `i`: a candidate of this shard is rolled for and
+ * queued here; one that lives on another shard (exact attribution) becomes a request to its owner */
+static void trace_candidate(Par *e, const reina_day_t *dp, int32_t g, uint32_t i, int level, int nxt) {
+    if (g < 0) return;
+    if (!gid_local(e, g)) {
+        xsend_push(e, rp_gid_shard((uint32_t)g), rp_xrec(gid_index(e, g), 0, (uint32_t)gid_of(e, i)));
+        return;
+    }
+    const uint32_t c = gid_index(e, g);
+    if (try_queue(e, c, (uint32_t)gid_of(e, i), dp)) {
+        queue_append(e, nxt, c);
+        if (level == 0) level1_append(e, c);
+    }
+}
+
+/* the infector and the infectees of agent i (level 0: a detected case; level 1: a contact queued at level 0) */
+static void trace_from(Par *e, const reina_day_t *dp, uint32_t i, int level, int nxt) {
+    trace_candidate(e, dp, e->buf.cold[i].infector, i, level, nxt);
+    if (!(e->buf.hot[i] & RH_HASLIST)) return;
+    for (int k = 0; k < REINA_INLINE_INFECTEES; k++)
+        trace_candidate(e, dp, e->buf.infectees[(size_t)i * REINA_INLINE_INFECTEES + k], i, level, nxt);
+    if (e->exact) {
+        for (int32_t n = e->buf.cold[i].first_infectee; n >= 0; n = (int32_t)e->buf.infectee_pool[2u * (uint32_t)n + 1u])
+            trace_candidate(e, dp, (int32_t)e->buf.infectee_pool[2u * (uint32_t)n], i, level, nxt);
+    } else {
+        for (int32_t c = e->buf.cold[i].first_infectee; c >= 0;) {
+            const int32_t next = e->buf.cold[c].next_sibling;
+            trace_candidate(e, dp, c, i, level, nxt);
+            c = next;
+        }
+    }
+}
+
+/* HealthcareSystem.iterate (main.pyx:514-558), the test queue: detection and level-0 tracing of every detected case */
+static void run_testing_level0(Par *e, const reina_day_t *dp) {
     int cur = dp->day & 1, nxt = cur ^ 1;
     uint32_t *q = cur ? e->buf.queue1 : e->buf.queue0;
     int lcur = cur ? REINA_L_QUEUE1 : REINA_L_QUEUE0;
@@ -373,47 +472,36 @@ static void run_testing(Par *e, const reina_day_t *dp) {
         CNT(e, REINA_C_ALL_DETECTED, age) += 1;
     }
     CTL(e, REINA_L_LEVEL1) = 0;
-    if (dp->testing_mode == RT_ALL_WITH_SYMPTOMS_CT) {
-        /* Q2: level 0 -- infector and infectees of every detected case */
-        for (int k = 0; k < n; k++) {
-            uint32_t i = q[k];
-            int32_t inf = e->buf.cold[i].infector;
-            if (inf >= 0 && try_queue(e, (uint32_t)inf, i, dp)) {
-                queue_append(e, nxt, (uint32_t)inf);
-                level1_append(e, (uint32_t)inf);
-            }
-            if (e->buf.hot[i] & RH_HASLIST) {
-                for (int k = 0; k < REINA_INLINE_INFECTEES; k++) {
-                    const int32_t c = e->buf.infectees[(size_t)i * REINA_INLINE_INFECTEES + k];
-                    if (c >= 0 && try_queue(e, (uint32_t)c, i, dp)) {
-                        queue_append(e, nxt, (uint32_t)c);
-                        level1_append(e, (uint32_t)c);
-                    }
-                }
-                for (int32_t c = e->buf.cold[i].first_infectee; c >= 0; c = e->buf.cold[c].next_sibling)
-                    if (try_queue(e, (uint32_t)c, i, dp)) {
-                        queue_append(e, nxt, (uint32_t)c);
-                        level1_append(e, (uint32_t)c);
-                    }
-            }
-        }
-        /* Q3: level 1 -- their infector and infectees, no further recursion */
-        int n1 = CTL(e, REINA_L_LEVEL1);
-        for (int k = 0; k < n1; k++) {
-            uint32_t i = e->buf.level1[k];
-            int32_t inf = e->buf.cold[i].infector;
-            if (inf >= 0 && try_queue(e, (uint32_t)inf, i, dp)) queue_append(e, nxt, (uint32_t)inf);
-            if (e->buf.hot[i] & RH_HASLIST) {
-                for (int k = 0; k < REINA_INLINE_INFECTEES; k++) {
-                    const int32_t c = e->buf.infectees[(size_t)i * REINA_INLINE_INFECTEES + k];
-                    if (c >= 0 && try_queue(e, (uint32_t)c, i, dp)) queue_append(e, nxt, (uint32_t)c);
-                }
-                for (int32_t c = e->buf.cold[i].first_infectee; c >= 0; c = e->buf.cold[c].next_sibling)
-                    if (try_queue(e, (uint32_t)c, i, dp)) queue_append(e, nxt, (uint32_t)c);
+    /* Q2: level 0 -- infector and infectees of every detected case */
+    if (dp->testing_mode == RT_ALL_WITH_SYMPTOMS_CT)
+        for (int k = 0; k < n; k++) trace_from(e, dp, q[k], 0, nxt);
+    CTL(e, lcur) = 0;
+}
+
+/* Q3: level 1 -- the infector and infectees of everybody queued at level 0, no further recursion */
+static void run_testing_level1(Par *e, const reina_day_t *dp) {
+    if (dp->testing_mode != RT_ALL_WITH_SYMPTOMS_CT) return;
+    const int nxt = (dp->day & 1) ^ 1;
+    int n1 = CTL(e, REINA_L_LEVEL1);
+    for (int k = 0; k < n1; k++) trace_from(e, dp, e->buf.level1[k], 1, nxt);
+}
+
+/* exact attribution: the tracing requests the other shards sent for candidates of this one */
+static void run_trace_requests(Par *e, const reina_day_t *dp, int level) {
+    const int nxt = (dp->day & 1) ^ 1;
+    for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+        if (sh == e->cfg.shard_rank) continue;
+        const uint64_t *seg = xseg(e, e->buf.xrecv, sh);
+        const uint32_t n = xrecv_count(e, sh);
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t c = rp_xrec_index(seg[1 + k]);
+            if (try_queue(e, c, rp_xrec_gid(seg[1 + k]), dp)) {
+                queue_append(e, nxt, c);
+                if (level == 0) level1_append(e, c);
             }
         }
     }
-    CTL(e, lcur) = 0;
+    xsend_reset(e);
 }
 
 /* HealthcareSystem.vaccinate_people (main.pyx:560-583): oldest first, persistent cursor (agents
@@ -843,7 +931,7 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
         int nr = (int)(wi[1] & 0xFF), v = (int)((wi[1] >> 8) & 0xFF), row = (int)(wi[1] >> 16);
         float src_inf = rp_u2f(wi[2]);
         uint32_t prio = rp_priority20(e->k0, e->k1, src, dp->day);
-        uint64_t key = rp_order_key(dp->day, prio, src);
+        uint64_t key = rp_order_key(dp->day, prio, (uint32_t)gid_of(e, src));
         for (int c = 0; c < nr; c++) {
             /* Philox2x32: half 0 = (place / age-range draw, transmission draw), half 1 = (shard + target draw, mask draw) */
             const uint32_t ckey = rp_contact_key(e->k0, e->k1);
@@ -868,6 +956,28 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
              * shard, then uniform agent of that shard (every shard holds 1/G of every age) */
             const uint32_t G = e->cfg.n_shards;
             uint32_t dest = r.v[1] % G;
+            if (dest != e->cfg.shard_rank && e->exact) {
+                /* exact attribution: the source completes did_infect (main.pyx:908-934) itself -- age ranges are global
+                 * knowledge, so it draws the target on the other shard and knows its age -- and sends (target, source id,
+                 * variant, list flag); all the destination adds is person_expose's test (main.pyx:239) and the claim */
+                const int32_t *das = e->shard_age_start[dest];
+                const uint32_t ds = (uint32_t)das[cmin], de = (uint32_t)das[cmax + 1];
+                if (de <= ds) continue;
+                if (!rp_chance(src_inf * e->psus_max[v] * d->infectiousness_multiplier[v], r.v[2])) continue;   /* (as below) */
+                const uint32_t t = ds + (r.v[1] / G) % (de - ds);
+                int age_t = cmin;
+                while (age_t < cmax && (uint32_t)das[age_t + 1] <= t) age_t++;
+                if (!rp_chance(src_inf * d->p_susceptibility[v][age_t] * d->infectiousness_multiplier[v], r.v[2])) continue;
+                const float mp = e->mask_p[row][place];
+                if (mp != 0.0f) {
+                    float a = mp * d->p_mask_protects_others[v];
+                    float b = mp * d->p_mask_protects_wearer[v];
+                    float pm = a + b - a * b;
+                    if (rp_chance(pm, r.v[3])) continue;
+                }
+                xsend_push(e, dest, rp_xrec(t, (uint32_t)v | (wi[3] << 2), (uint32_t)gid_of(e, src)));
+                continue;
+            }
             if (dest != e->cfg.shard_rank) {
                 /* source-side part of did_infect: everything that does not depend on the target;
                  * the target's susceptibility is applied by the destination as p_sus / psus_max */
@@ -916,11 +1026,52 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
             }
             uint32_t *cd = e->buf.candidates + 4u * (uint32_t)CTL(e, REINA_L_CAND)++;
             cd[0] = t;
-            cd[1] = src;
+            cd[1] = (uint32_t)gid_of(e, src);
             cd[2] = (uint32_t)v | (wi[3] << 8);
             cd[3] = prio;
         }
     }
+}
+
+/* exact attribution: the contact records the other shards sent.  A record stands for a contact that passed did_infect's
+ * whole test at its source; here it meets person_expose's test (only a never-infected agent can be infected,
+ * main.pyx:239) and competes for the target like a local contact, under its source's own key */
+static void run_remote_exact(Par *e, const reina_day_t *dp) {
+    for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+        if (sh == e->cfg.shard_rank) continue;
+        const uint64_t *seg = xseg(e, e->buf.xrecv, sh);
+        const uint32_t n = xrecv_count(e, sh);
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t t = rp_xrec_index(seg[1 + k]), fl = rp_xrec_flags(seg[1 + k]), src = rp_xrec_gid(seg[1 + k]);
+            if (RH_STATE(e->buf.hot[t]) != RS_SUSCEPTIBLE) continue;
+            const uint32_t prio = rp_priority20(e->shard_k0[sh], e->shard_k1[sh], src & RP_GID_INDEX_MASK, dp->day);
+            const uint64_t key = rp_order_key(dp->day, prio, src);
+            if (key < e->buf.cold[t].claim) e->buf.cold[t].claim = key;
+            if ((uint32_t)CTL(e, REINA_L_CAND) >= e->cfg.max_candidates) {
+                set_problem(e, REINA_PROBLEM_CANDIDATE_OVERFLOW);
+                continue;
+            }
+            uint32_t *cd = e->buf.candidates + 4u * (uint32_t)CTL(e, REINA_L_CAND)++;
+            cd[0] = t;
+            cd[1] = src;
+            cd[2] = (fl & 3u) | ((fl >> 2) << 8);
+            cd[3] = prio;
+        }
+    }
+    xsend_reset(e);
+}
+
+/* exact attribution: the feedback records of the day's cross-shard infections -- the sources that live here take their
+ * infectees (person_infect's source half, main.pyx:219-233), so that counts and lists are true before the next morning */
+static void run_feedback(Par *e) {
+    for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+        if (sh == e->cfg.shard_rank) continue;
+        const uint64_t *seg = xseg(e, e->buf.xrecv, sh);
+        const uint32_t n = xrecv_count(e, sh);
+        for (uint32_t k = 0; k < n; k++)
+            source_gains_infectee(e, rp_xrec_index(seg[1 + k]), (int32_t)rp_xrec_gid(seg[1 + k]), rp_xrec_flags(seg[1 + k]) >> 2);
+    }
+    xsend_reset(e);
 }
 
 /* cross-shard pressure aimed at this shard (summed over all shards by the caller): attempt k of
@@ -929,6 +1080,10 @@ static void run_contacts(Par *e, const reina_day_t *dp) {
 static void run_remote(Par *e, const reina_day_t *dp) {
     const reina_disease_t *d = &e->dis;
     if (e->cfg.n_shards <= 1) return;
+    if (e->exact) {
+        run_remote_exact(e, dp);
+        return;
+    }
     uint32_t idx = 0;
     for (uint32_t rg = 0; rg < e->n_ranges; rg++)
         for (uint32_t v = 0; v < e->cfg.nr_variants; v++) {
@@ -1021,7 +1176,7 @@ static void run_install(Par *e, const reina_day_t *dp) {
     }
     /* tomorrow's mirror-table sizes: about twice this shard's share of today's cross-shard attempts of
      * the cell (pressure holds the sums over all shards by now), a power of two in [8, mirror_slots] */
-    if (e->cfg.n_shards > 1)
+    if (e->cfg.n_shards > 1 && !e->exact)
         for (uint32_t cell = 0; cell < REINA_MIRROR_CELLS; cell++) {
             uint32_t tot = 0;
             for (uint32_t dest = 0; dest < e->cfg.n_shards; dest++) {
@@ -1035,11 +1190,9 @@ static void run_install(Par *e, const reina_day_t *dp) {
         }
 }
 
-/* Context.iterate (main.pyx:2011-2018) in the parallel formulation, first half */
-int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
-    (void)stream;
-    if (!e->bound) return REINA_E_NOT_BOUND;
-    if (dp->day >= REINA_MAX_DAYS) return REINA_E_INVALID;   /* the 12-bit day tag of rp_order_key, as the engine */
+/* Context.iterate (main.pyx:2011-2018) in the parallel formulation, as the phases between which a sharded population
+ * exchanges (include/reina_hip.h: reina_step_phase) */
+static void open_day(Par *e, const reina_day_t *dp) {
     if (dp->history_row) memcpy(dp->history_row, e->buf.counters, sizeof(int32_t) * REINA_COUNTER_WORDS);
     uint32_t import_base = 0;
     SC(e, REINA_S_DAY) = (int32_t)dp->day + 1;
@@ -1066,28 +1219,66 @@ int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
     CTL(e, REINA_L_ICU_ADMIT) = 0;
     memset(e->buf.pressure, 0, sizeof(int32_t) * REINA_EXCHANGE_WORDS(e->cfg.n_shards, e->hosp_ranges));
     run_imports(e, dp, 0, &import_base);
-    run_testing(e, dp);
-    run_vaccinations(e, dp);
-    /* a sharded population's free capacity at day open and (below) its demand travel with the pressure all-reduce */
-    const int32_t free_beds_open = SC(e, REINA_S_AVAILABLE_BEDS), free_icu_open = SC(e, REINA_S_AVAILABLE_ICU);
-    run_scan(e, dp);
-    run_contacts(e, dp);
-    if (e->cfg.n_shards > 1) {
-        e->buf.pressure[REINA_PRESSURE_FREE_BEDS(e->cfg.shard_rank)] = free_beds_open;
-        e->buf.pressure[REINA_PRESSURE_FREE_ICU(e->cfg.shard_rank)] = free_icu_open;
-        e->buf.pressure[REINA_PRESSURE_DEMAND_BEDS(e->cfg.shard_rank)] = CTL(e, REINA_L_HOSP_ADMIT);
-        e->buf.pressure[REINA_PRESSURE_DEMAND_ICU(e->cfg.shard_rank)] = CTL(e, REINA_L_ICU_ADMIT);
-        publish_hospital_maps(e);
+}
+
+int par_step_phase(Par *e, const reina_day_t *dp, int phase, void *stream) {
+    (void)stream;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    if (dp->day >= REINA_MAX_DAYS) return REINA_E_INVALID;   /* the 12-bit day tag of rp_order_key, as the engine */
+    /* the exchanges of a tracing day under exact attribution: requests at level 0, then at level 1 */
+    const int xtrace = e->exact && dp->testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
+    switch (phase) {
+    case REINA_PH_OPEN:
+        open_day(e, dp);
+        run_testing_level0(e, dp);
+        return xtrace ? REINA_X_ALLTOALL : 0;
+    case REINA_PH_TRACE:
+        if (xtrace) run_trace_requests(e, dp, 0);
+        run_testing_level1(e, dp);
+        return xtrace ? REINA_X_ALLTOALL : 0;
+    case REINA_PH_MAIN: {
+        if (xtrace) run_trace_requests(e, dp, 1);
+        run_vaccinations(e, dp);
+        /* a sharded population's free capacity at day open and (below) its demand travel with the pressure all-reduce */
+        const int32_t free_beds_open = SC(e, REINA_S_AVAILABLE_BEDS), free_icu_open = SC(e, REINA_S_AVAILABLE_ICU);
+        run_scan(e, dp);
+        run_contacts(e, dp);
+        if (e->cfg.n_shards > 1) {
+            e->buf.pressure[REINA_PRESSURE_FREE_BEDS(e->cfg.shard_rank)] = free_beds_open;
+            e->buf.pressure[REINA_PRESSURE_FREE_ICU(e->cfg.shard_rank)] = free_icu_open;
+            e->buf.pressure[REINA_PRESSURE_DEMAND_BEDS(e->cfg.shard_rank)] = CTL(e, REINA_L_HOSP_ADMIT);
+            e->buf.pressure[REINA_PRESSURE_DEMAND_ICU(e->cfg.shard_rank)] = CTL(e, REINA_L_ICU_ADMIT);
+            publish_hospital_maps(e);
+        }
+        return ((e->cfg.n_shards > 1 || e->coll_fn) ? REINA_X_ALLREDUCE : 0) | (e->exact ? REINA_X_ALLTOALL : 0);
+    }
+    case REINA_PH_END:
+        run_remote(e, dp);     /* (a stand-in source's infectee-list flag: its word before the day's bed / ICU walk) */
+        run_hospital(e, dp);
+        run_install(e, dp);
+        return e->exact ? REINA_X_ALLTOALL : 0;
+    case REINA_PH_FEEDBACK:
+        if (e->exact) run_feedback(e);
+        return 0;
+    }
+    return REINA_E_INVALID;
+}
+
+/* the two halves of a day around its one all-reduce (a population without exact attribution) */
+int par_step_day_begin(Par *e, const reina_day_t *dp, void *stream) {
+    if (e->exact) return REINA_E_INVALID;
+    for (int ph = REINA_PH_OPEN; ph <= REINA_PH_MAIN; ph++) {
+        const int rc = par_step_phase(e, dp, ph, stream);
+        if (rc < 0) return rc;
     }
     return 0;
 }
-
-/* second half: after the caller has summed `pressure` over the shards */
 int par_step_day_end(Par *e, const reina_day_t *dp, void *stream) {
-    (void)stream;
-    run_remote(e, dp);     /* (a stand-in source's infectee-list flag: its word before the day's bed / ICU walk) */
-    run_hospital(e, dp);
-    run_install(e, dp);
+    if (e->exact) return REINA_E_INVALID;
+    for (int ph = REINA_PH_END; ph <= REINA_PH_FEEDBACK; ph++) {
+        const int rc = par_step_phase(e, dp, ph, stream);
+        if (rc < 0) return rc;
+    }
     return 0;
 }
 
@@ -1096,14 +1287,25 @@ int par_set_collective(Par *e, reina_allreduce_fn fn, void *comm) {
     e->coll_comm = comm;
     return 0;
 }
+int par_set_alltoall(Par *e, reina_alltoall_fn fn, void *comm) {
+    e->a2a_fn = fn;
+    e->a2a_comm = comm;
+    return 0;
+}
 
 int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
-    int rc = par_step_day_begin(e, dp, stream);
-    if (rc) return rc;
-    if (e->coll_fn && e->coll_fn(e->buf.pressure, e->buf.pressure, REINA_EXCHANGE_WORDS(e->cfg.n_shards, e->hosp_ranges), 2, 0, e->coll_comm,
-                                 stream) != 0)
-        return REINA_E_INVALID;
-    return par_step_day_end(e, dp, stream);
+    for (int ph = 0; ph < REINA_PH_NR; ph++) {
+        const int rc = par_step_phase(e, dp, ph, stream);
+        if (rc < 0) return rc;
+        if ((rc & REINA_X_ALLREDUCE) && e->coll_fn &&
+            e->coll_fn(e->buf.pressure, e->buf.pressure, REINA_EXCHANGE_WORDS(e->cfg.n_shards, e->hosp_ranges), 2, 0, e->coll_comm, stream) != 0)
+            return REINA_E_INVALID;
+        if (rc & REINA_X_ALLTOALL) {
+            if (!e->a2a_fn) return REINA_E_NOT_BOUND;   /* exact attribution cannot run without its exchange */
+            if (e->a2a_fn(e->buf.xsend, e->buf.xrecv, (size_t)e->cfg.xchg_cap + 1u, 4, e->a2a_comm, stream) != 0) return REINA_E_INVALID;
+        }
+    }
+    return 0;
 }
 
 int par_run_days(Par *e, const reina_day_t *days, uint32_t n, void *stream) {

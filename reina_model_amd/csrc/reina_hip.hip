@@ -93,7 +93,7 @@ static bool kind_timed(int today, int kind) {
     if (today < 0) return false;
     if (today == REINA_PK_NR || today == kind) return true;
     // kernels that do not run every day are timed on k_open's days
-    if (today == REINA_PK_HOSPITAL && (kind == REINA_PK_REMOTE || kind == REINA_PK_HOSP_SORT || kind == REINA_PK_HOSP_WALK)) return true;
+    if (today == REINA_PK_HOSPITAL && (kind == REINA_PK_REMOTE || kind == REINA_PK_HOSP_SORT || kind == REINA_PK_HOSP_WALK || kind == REINA_PK_XCHG)) return true;
     return today == REINA_PK_OPEN && (kind == REINA_PK_TRACE1 || kind == REINA_PK_VACCINATE);
 }
 
@@ -194,7 +194,7 @@ static void count_row_for(float nr_contacts, uint32_t *thr, uint8_t *guide) {
 
 extern "C" {
 
-int reina_abi_version(void) { return 4; }
+int reina_abi_version(void) { return 5; }
 
 #ifdef REINA_ABLATE
 int reina_debug_ablate(uint32_t bits) {   // diagnostic builds only (tools/ablate_day.py)
@@ -335,6 +335,28 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
             if (disease->p_susceptibility[v][a] > m) m = disease->p_susceptibility[v][a];
         e->h_params.psus_max[v] = m;
     }
+    // exact cross-shard attribution (include/reina_hip.h): global ids in the link fields, records exchanged between the shards
+    e->exact = cfg->exact_attribution != 0 && e->cfg.n_shards > 1;
+    e->h_params.gid_mask = 0xFFFFFFFFu;
+    if (e->exact) {
+        if (!cfg->shard_age_start || cfg->xchg_cap == 0 || cfg->pool_cap == 0 || cfg->n_agents > RP_GID_INDEX_MASK) {
+            g_last_error = "exact attribution needs shard_age_start, xchg_cap > 0, pool_cap > 0 and fewer than 2^27 agents per shard";
+            delete e;
+            return REINA_E_INVALID;
+        }
+        e->h_params.exact = 1u;
+        e->h_params.gid_base = e->cfg.shard_rank << RP_GID_SHIFT;
+        e->h_params.gid_mask = RP_GID_INDEX_MASK;
+        e->h_params.xchg_cap = cfg->xchg_cap;
+        e->h_params.pool_cap = cfg->pool_cap;
+        std::memcpy(e->h_params.shard_age_start, cfg->shard_age_start, sizeof(int32_t) * (size_t)e->cfg.n_shards * (REINA_MAX_AGES + 1));
+        for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+            const uint64_t ss = rp_shard_seed(cfg->seed, sh);
+            e->h_params.shard_k0[sh] = (uint32_t)ss;
+            e->h_params.shard_k1[sh] = (uint32_t)(ss >> 32);
+        }
+    }
+    e->cfg.shard_age_start = nullptr;   // (the caller's array is not kept)
     e->h_params.max_work_items = cfg->max_work_items;
     e->h_params.max_candidates = cfg->max_candidates;
     {   // the space above the per-wave regions: half (at most 2^20 records) for records that overflow a wave's
@@ -612,8 +634,14 @@ static uint32_t day_blocks_for(uint32_t n_agents, uint32_t K, uint32_t n_cus) {
 // One day's launches for K engine instances at once (K = 1: a single engine; K > 1: a group of
 // identically configured engines, one launch per phase for all of them, member = blockIdx.y).
 // `e` is the representative engine: geometry, scenario flags, optional second stream.
-static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp,
-                            uint32_t hist_slot, hipStream_t s) {
+// The day comes in the PHASES of include/reina_hip.h (reina_step_phase): between them a sharded population exchanges.
+struct DayGeom {   // what the launches of a day's first phases agree on (a function of the engine and the day alone)
+    int weekly_own;            // k_open's import roles (k_testing.inc: open_role)
+    uint32_t stream_imports;   // workgroups of k_day's launch that place the weekly imports beside the stream
+    uint32_t day_blocks;       // streaming workgroups of k_day
+    bool xtrace;               // exact attribution on a contact-tracing day: tracing level by level, an exchange behind each
+};
+static int day_geometry(reina_engine_t *e, uint32_t K, const reina_day_t &dp, DayGeom *g) {
     const uint32_t N = e->cfg.n_agents;
     if (dp.day >= REINA_MAX_DAYS) {
         // claim / mirror keys carry the day in 12 bits (rp_order_key) and claim[] is never cleared: from day
@@ -625,7 +653,6 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         g_last_error = "n_import_batches / n_vaccinations out of range";
         return REINA_E_INVALID;
     }
-    const int today = profiled_kind(e, dp.day);
     if (dp.testing_mode != RT_NO_TESTING) e->testing_ever = true;
     uint32_t n_pre = 0, n_post = 0;
     for (uint32_t b = 0; b < dp.n_import_batches; b++)
@@ -643,67 +670,126 @@ static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K
         if (weekly_own) weekly_own = w;
         else if (n_pre > 0 && w > 1) weekly_own = -(w - 1);
     }
-    // the day's opening: roles (0 opens the day, 1 weekly imports, 2.. the test queue) by arrival ticket
-    // (groups: the members share the chip, so each gets proportionally fewer workgroups per phase)
-    int tg = grid_for(N / 64 + 1, PRO_THREADS, 64);
-    if (K > 1 && tg > (int)(e->n_cus / K)) tg = e->n_cus / K > 0 ? (int)(e->n_cus / K) : 1;
-    const bool ct = dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
-    const uint32_t scan_tiles = ((N >> 2) + 127u) / 128u;
     uint32_t day_blocks = day_blocks_for(N, K, e->n_cus);
     // weekly imports on a day without intervention imports are placed in k_day's launch, beside the stream, by workgroups
-    // of their own behind the streaming ones (k_open.inc: deferred placement); all of them fit the chip together
+    // of their own behind the streaming ones (k_open.inc: deferred placement); all of them fit the chip together.
+    // (Their records go to the shared candidate overflow list: only when the day's imports fit it with room to spare for real
+    // overflow records -- a caller of the C ABI may have sized max_candidates tightly -- else the opening launch places them)
     uint32_t stream_imports = 0;
-    if (weekly_own > 0 && dp.day + 1u < REINA_MAX_DAYS && !e->imports_in_open) {
+    if (weekly_own > 0 && dp.day + 1u < REINA_MAX_DAYS && !e->imports_in_open && (uint64_t)n_post * 2u <= e->h_params.cand_ovf_cap) {
         stream_imports = K == 1 ? (uint32_t)weekly_own : 1u;
         const uint32_t cap = K > 1 ? (e->n_cus / K > 0 ? e->n_cus / K : 1u) : e->n_cus;
         if (day_blocks + stream_imports > cap && cap > stream_imports) day_blocks = cap - stream_imports;
         weekly_own = OPEN_WEEKLY_IN_STREAM;
     }
+    g->weekly_own = weekly_own;
+    g->stream_imports = stream_imports;
+    g->day_blocks = day_blocks;
+    g->xtrace = e->exact && dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
+    return REINA_OK;
+}
+
+// REINA_PH_OPEN: the day's opening -- roles (0 opens the day, 1 weekly imports, 2.. the test queue) by arrival ticket
+static int launch_day_open(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, uint32_t hist_slot, hipStream_t s) {
+    DayGeom geo;
+    if (int rc = day_geometry(e, K, dp, &geo)) return rc;
+    const uint32_t N = e->cfg.n_agents;
+    const int today = profiled_kind(e, dp.day);
+    const int weekly_own = geo.weekly_own;
+    // (groups: the members share the chip, so each gets proportionally fewer workgroups per phase)
+    int tg = grid_for(N / 64 + 1, PRO_THREADS, 64);
+    if (K > 1 && tg > (int)(e->n_cus / K)) tg = e->n_cus / K > 0 ? (int)(e->n_cus / K) : 1;
+    const bool ct = dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
+    const int helpers = weekly_own == OPEN_WEEKLY_IN_STREAM ? 0 : weekly_own > 0 ? weekly_own : -weekly_own;
+    const int g0 = 1 + (helpers > 1 ? helpers : 1), g = g0 + tg;
+    // roles by arrival ticket unless the launch is resident as a whole -- and, measured, for small populations too
+    // (HUS year: k_open 10.4 us a day with tickets, 11.2 by block number; 10^8 agents: 14.6 against 14.1)
+    const int open_tickets = (K > 1 || g > (int)e->n_cus || e->open_tickets || N <= 8000000u) ? 1 : 0;
+    if (!e->testing_ever) {
+        LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g0, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0, open_tickets);
+    } else if (ct && N <= 8000000u && !geo.xtrace) {
+        LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 3, open_tickets);  // detects + traces, both levels
+    } else if (ct) {
+        // detects + traces level 0; level 1 by a launch of its own (exact attribution: behind the exchange of the level-0 requests)
+        LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 2, open_tickets);
+        if (!geo.xtrace) LAUNCH_DAY(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, dp);
+    } else {
+        LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 1, open_tickets);
+    }
+    HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+
+// workgroups of a launch that takes in the records of an exchange (k_xtrace, k_feedback)
+static int xchg_grid(const reina_engine_t *e) { return grid_for(e->cfg.xchg_cap * (e->cfg.n_shards - 1u) / 4u + 1u, 256, 128); }
+
+// REINA_PH_TRACE (exact attribution, contact-tracing days): the level-0 requests of the other shards, then level 1
+static int launch_day_trace(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, hipStream_t s) {
+    DayGeom geo;
+    if (int rc = day_geometry(e, K, dp, &geo)) return rc;
+    if (!geo.xtrace) return REINA_OK;
+    const int today = profiled_kind(e, dp.day);
+    LAUNCH_DAY(e, today, REINA_PK_XCHG, k_xtrace, dim3(xchg_grid(e), K), dim3(256), 0, s, dp, 0);
+    LAUNCH_DAY(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(e->cfg.n_agents / 64 + 1, 256, 256), K), dim3(256), 0, s, dp);
+    HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+
+// REINA_PH_MAIN: (the level-1 requests of the other shards,) vaccination, the stream with the contact sampling, and a sharded
+// population's event maps for the all-reduce
+static int launch_day_main(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, hipStream_t s) {
+    DayGeom geo;
+    if (int rc = day_geometry(e, K, dp, &geo)) return rc;
+    const int today = profiled_kind(e, dp.day);
+    if (geo.xtrace) LAUNCH_DAY(e, today, REINA_PK_XCHG, k_xtrace, dim3(xchg_grid(e), K), dim3(256), 0, s, dp, 1);
+    const uint32_t day_blocks = geo.day_blocks, stream_imports = geo.stream_imports;
     uint32_t lds_rows = K > 1 ? e->group_lds_rows : e->h_tables.n_rows;   // (a member stages min(its own rows, lds_rows))
     if (lds_rows > REINA_LDS_ROWS) lds_rows = REINA_LDS_ROWS;
     if (e->lds_rows_cap && lds_rows > e->lds_rows_cap) lds_rows = e->lds_rows_cap;
     uint32_t lds_crows = K > 1 ? e->group_lds_crows : e->h_tables.n_crows;
     if (lds_crows > REINA_LDS_CROWS) lds_crows = REINA_LDS_CROWS;
     if (e->lds_rows_cap && lds_crows > e->lds_rows_cap) lds_crows = e->lds_rows_cap;
-    {
-        const int helpers = weekly_own == OPEN_WEEKLY_IN_STREAM ? 0 : weekly_own > 0 ? weekly_own : -weekly_own;
-        const int g0 = 1 + (helpers > 1 ? helpers : 1), g = g0 + tg;
-        // roles by arrival ticket unless the launch is resident as a whole -- and, measured, for small populations too
-        // (HUS year: k_open 10.4 us a day with tickets, 11.2 by block number; 10^8 agents: 14.6 against 14.1)
-        const int open_tickets = (K > 1 || g > (int)e->n_cus || e->open_tickets || N <= 8000000u) ? 1 : 0;
-        if (!e->testing_ever) {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g0, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 0, open_tickets);
-        } else if (ct && N <= 8000000u) {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 3, open_tickets);  // detects + traces, both levels
-        } else if (ct) {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 2, open_tickets);  // detects + traces level 0
-            LAUNCH_DAY(e, today, REINA_PK_TRACE1, k_test_trace1, dim3(grid_for(N / 64 + 1, 256, 256), K), dim3(256), 0, s, dp);
-        } else {
-            LAUNCH_DAY(e, today, REINA_PK_OPEN, k_open, dim3(g, K), dim3(PRO_THREADS), 0, s, dp, hist_slot, weekly_own, 1, open_tickets);
+    // a vaccination programme: its pass over the agents comes after the test queue and before the stream
+    // (HealthcareSystem.iterate, main.pyx:514-558)
+    if (dp.n_vaccinations) {
+        // ONE programme whose number of the day exceeds a step of 16 x 1024 agents, a single engine: a chain of workgroups, one
+        // step each, with room for a third more agents than the number (k_open.inc: pro_vaccinate_chain); otherwise one workgroup
+        // (the number as the kernel clips it: a programme whose window holds fewer agents never needs the chain)
+        uint32_t vg = 1;
+        const reina_vaccination_t &v0 = dp.vaccinations[0];
+        const uint32_t window = v0.idx_end > v0.idx_start ? v0.idx_end - v0.idx_start : 0u;
+        const uint32_t nr0 = v0.nr < window ? v0.nr : window;
+        if (K == 1 && dp.n_vaccinations == 1 && nr0 > VACC_CHUNKS * PRO_THREADS && e->cfg.max_work_items >= 4096 && !e->vacc_one_wg) {
+            vg = (nr0 + nr0 / 3u) / (VACC_CHUNKS * PRO_THREADS) + 1u;
+            if (vg > e->n_cus) vg = e->n_cus;
+            if (vg > 256u) vg = 256u;
         }
-        // a vaccination programme: its pass over the agents comes after the test queue and before the stream
-        // (HealthcareSystem.iterate, main.pyx:514-558)
-        if (dp.n_vaccinations) {
-            // ONE programme whose number of the day exceeds a step of 16 x 1024 agents, a single engine: a chain of workgroups, one
-            // step each, with room for a third more agents than the number (k_open.inc: pro_vaccinate_chain); otherwise one workgroup
-            uint32_t vg = 1;
-            if (K == 1 && dp.n_vaccinations == 1 && dp.vaccinations[0].nr > VACC_CHUNKS * PRO_THREADS && e->cfg.max_work_items >= 4096 && !e->vacc_one_wg) {
-                vg = (dp.vaccinations[0].nr + dp.vaccinations[0].nr / 3u) / (VACC_CHUNKS * PRO_THREADS) + 1u;
-                if (vg > e->n_cus) vg = e->n_cus;
-                if (vg > 256u) vg = 256u;
-            }
-            LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(vg, K), dim3(PRO_THREADS), 0, s, dp);
-        }
-        LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks + stream_imports, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows,
-                   e->day_sparse_below, e->day_flags, stream_imports);
+        LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(vg, K), dim3(PRO_THREADS), 0, s, dp);
     }
+    LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks + stream_imports, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows,
+               e->day_sparse_below, e->day_flags, stream_imports);
     e->cur_scan_waves = day_blocks * DAY_WAVES;   // (the day's later launches walk the per-wave slices)
     if (e->cfg.n_shards > 1) {
         // a sharded population: its event buckets sorted and their maps written to the exchange block BEFORE the all-reduce
         const uint32_t n_walk = (e->h_params.hosp_ranges + 15u) / 16u;
         LAUNCH_DAY(e, today, REINA_PK_HOSP_SORT, k_hosp_presort, dim3(n_walk, K), dim3(HOSP_THREADS), (size_t)HOSP_P_THREADS * HOSP_P_E * 8, s, dp);
     }
-    (void)scan_tiles;
+    HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+
+static int launch_day_begin(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp,
+                            uint32_t hist_slot, hipStream_t s) {
+    if (int rc = launch_day_open(e, refs, K, dp, hist_slot, s)) return rc;
+    if (int rc = launch_day_trace(e, refs, K, dp, s)) return rc;
+    return launch_day_main(e, refs, K, dp, s);
+}
+
+// REINA_PH_FEEDBACK (exact attribution): the sources of the day's cross-shard infections take their infectees
+static int launch_day_feedback(reina_engine_t *e, const MemberRef *refs, uint32_t K, const reina_day_t &dp, hipStream_t s) {
+    if (!e->exact) return REINA_OK;
+    const int today = profiled_kind(e, dp.day);
+    LAUNCH_DAY(e, today, REINA_PK_XCHG, k_feedback, dim3(xchg_grid(e), K), dim3(256), 0, s, dp);
     HIP_CHECK(hipGetLastError());
     return REINA_OK;
 }
@@ -752,15 +838,51 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
     return REINA_OK;
 }
 
+int reina_step_phase(reina_engine_t *e, const reina_day_t *day, int phase, void *stream) {
+    if (!e || !day) return REINA_E_INVALID;
+    if (!e->bound) return REINA_E_NOT_BOUND;
+    hipStream_t s = (hipStream_t)stream;
+    const bool xtrace = e->exact && day->testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
+    int rc;
+    switch (phase) {
+    case REINA_PH_OPEN:
+        rc = launch_day_open(e, e->d_ref, 1, *day, 0, s);
+        return rc ? rc : (xtrace ? REINA_X_ALLTOALL : 0);
+    case REINA_PH_TRACE:
+        rc = launch_day_trace(e, e->d_ref, 1, *day, s);
+        return rc ? rc : (xtrace ? REINA_X_ALLTOALL : 0);
+    case REINA_PH_MAIN:
+        rc = launch_day_main(e, e->d_ref, 1, *day, s);
+        // (a single shard with a collective set exchanges too: the one-GPU box exercises the call)
+        return rc ? rc : (((e->cfg.n_shards > 1 || e->coll_fn) ? REINA_X_ALLREDUCE : 0) | (e->exact ? REINA_X_ALLTOALL : 0));
+    case REINA_PH_END:
+        rc = launch_day_end(e, e->d_ref, 1, *day, s);
+        return rc ? rc : (e->exact ? REINA_X_ALLTOALL : 0);
+    case REINA_PH_FEEDBACK:
+        return launch_day_feedback(e, e->d_ref, 1, *day, s);
+    }
+    g_last_error = "phase out of range";
+    return REINA_E_INVALID;
+}
+
+// the two halves of a day around its one all-reduce (a population without exact attribution)
 int reina_step_day_begin(reina_engine_t *e, const reina_day_t *day, void *stream) {
     if (!e || !day) return REINA_E_INVALID;
     if (!e->bound) return REINA_E_NOT_BOUND;
+    if (e->exact) {
+        g_last_error = "exact attribution: a day has more than one exchange -- step it by reina_step_phase (or reina_step_day with reina_set_alltoall)";
+        return REINA_E_INVALID;
+    }
     return launch_day_begin(e, e->d_ref, 1, *day, 0, (hipStream_t)stream);
 }
 
 int reina_step_day_end(reina_engine_t *e, const reina_day_t *day, void *stream) {
     if (!e || !day) return REINA_E_INVALID;
     if (!e->bound) return REINA_E_NOT_BOUND;
+    if (e->exact) {
+        g_last_error = "exact attribution: a day has more than one exchange -- step it by reina_step_phase (or reina_step_day with reina_set_alltoall)";
+        return REINA_E_INVALID;
+    }
     return launch_day_end(e, e->d_ref, 1, *day, (hipStream_t)stream);
 }
 
@@ -771,19 +893,38 @@ int reina_set_collective(reina_engine_t *e, reina_allreduce_fn allreduce, void *
     return REINA_OK;
 }
 
+int reina_set_alltoall(reina_engine_t *e, reina_alltoall_fn alltoall, void *comm) {
+    if (!e) return REINA_E_INVALID;
+    e->a2a_fn = alltoall;
+    e->a2a_comm = comm;
+    return REINA_OK;
+}
+
 int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
-    int rc = reina_step_day_begin(e, day, stream);
-    if (rc) return rc;
-    if (e->coll_fn) {
-        // the only per-day exchange of a sharded population, queued on the day stream itself
-        const int r = e->coll_fn(e->buf.pressure, e->buf.pressure, e->exchange_words, 2 /* ncclInt32 */, 0 /* ncclSum */,
-                                 e->coll_comm, stream);
-        if (r != 0) {
-            g_last_error = "collective failed with code " + std::to_string(r);
-            return REINA_E_HIP;
+    for (int ph = 0; ph < REINA_PH_NR; ph++) {
+        const int need = reina_step_phase(e, day, ph, stream);
+        if (need < 0) return need;
+        // the exchanges of a sharded population, queued on the day stream itself
+        if ((need & REINA_X_ALLREDUCE) && e->coll_fn) {
+            const int r = e->coll_fn(e->buf.pressure, e->buf.pressure, e->exchange_words, 2 /* ncclInt32 */, 0 /* ncclSum */, e->coll_comm, stream);
+            if (r != 0) {
+                g_last_error = "collective failed with code " + std::to_string(r);
+                return REINA_E_HIP;
+            }
+        }
+        if (need & REINA_X_ALLTOALL) {
+            if (!e->a2a_fn) {
+                g_last_error = "exact attribution: no all-to-all set (reina_set_alltoall) -- step the day by reina_step_phase and exchange buffers.xsend / xrecv yourself";
+                return REINA_E_NOT_BOUND;
+            }
+            const int r = e->a2a_fn(e->buf.xsend, e->buf.xrecv, (size_t)e->cfg.xchg_cap + 1u, 4 /* ncclInt64 */, e->a2a_comm, stream);
+            if (r != 0) {
+                g_last_error = "all-to-all failed with code " + std::to_string(r);
+                return REINA_E_HIP;
+            }
         }
     }
-    return reina_step_day_end(e, day, stream);
+    return REINA_OK;
 }
 
 int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, void *stream) {

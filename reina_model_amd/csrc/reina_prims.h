@@ -382,6 +382,25 @@ RP_HD void rp_sat_unpack(uint64_t v, rp_sat_t *fb, rp_sat_t *fc) {
     fc->m = cm == 0x3FFFu ? RP_SAT_NEG : (int)cm - 8192;
 }
 
+// ------------------------------------------------------------------ exact cross-shard attribution (include/reina_hip.h)
+// A global id: [shard : 4][index : 27], non-negative as an int32.  `gid_base` = shard << 27 of the engine's own shard when its
+// population keeps global ids (exact attribution), 0 otherwise; `gid_mask` = the index bits then, all ones otherwise -- so the
+// same three expressions serve a population that keeps plain local indices (unsharded, or mirror attribution).
+#define RP_GID_SHIFT 27
+#define RP_GID_INDEX_MASK ((1u << RP_GID_SHIFT) - 1u)
+RP_HD uint32_t rp_gid_is_local(uint32_t gid, uint32_t gid_base, uint32_t gid_mask) { return (gid & ~gid_mask) == gid_base; }
+RP_HD uint32_t rp_gid_shard(uint32_t gid) { return gid >> RP_GID_SHIFT; }
+// One 8-byte record of an exchange segment: `index` at the RECEIVING shard (27 bits), 5 bits of flags, a global id (31 bits):
+//   contact record   (target, flags = variant | source-keeps-a-list << 2, source gid)   source's shard -> target's
+//   feedback record  (source, flags = source-keeps-a-list << 2, infectee gid)            target's shard -> source's
+//   tracing request  (candidate, flags = 0, tracer gid)                                   tracer's shard -> candidate's
+RP_HD uint64_t rp_xrec(uint32_t index, uint32_t flags, uint32_t gid) {
+    return ((uint64_t)gid << 32) | ((uint64_t)(flags & 31u) << RP_GID_SHIFT) | (uint64_t)(index & RP_GID_INDEX_MASK);
+}
+RP_HD uint32_t rp_xrec_index(uint64_t r) { return (uint32_t)r & RP_GID_INDEX_MASK; }
+RP_HD uint32_t rp_xrec_flags(uint64_t r) { return ((uint32_t)r >> RP_GID_SHIFT) & 31u; }
+RP_HD uint32_t rp_xrec_gid(uint64_t r) { return (uint32_t)(r >> 32); }
+
 // candidate "source id" of an infection realised from cross-shard pressure (no local infector)
 #define RP_REMOTE_SRC 0x80000000u
 #define RP_MIRROR_PROBES 16u      // probes per cell of the mirror table (tables are kept >= ~40 % full)

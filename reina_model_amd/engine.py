@@ -43,16 +43,23 @@ S_INFECTED_BY_VARIANT = 24
 S_NR = 32
 COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 48 + MAX_AGES   # REINA_L_NR (48 named words and cursors + the detections-by-age side block)
+L_POOL = 26        # control word (exact attribution): nodes of infectee_pool handed out
 L_HOSP_PEAK = 12   # control word: bed / ICU event count of the busiest day on which the events' order mattered
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
-ABI_VERSION = 4   # reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays; round 4: the two per-agent bit planes)
+ABI_VERSION = 5   # reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays; round 4: the two per-agent bit planes; round 5: exact cross-shard attribution -- exchange buffers, infectee pool, reina_step_phase)
 INLINE_INFECTEES = 8   # REINA_INLINE_INFECTEES
 COLD_WORDS = 8         # sizeof(reina_cold_t) / 4: claim (2 words), infector, n_infected, onset_days, vacc_day, first_infectee, next_sibling
 COLD_FIELDS = dict(infector=2, n_infected=3, onset_days=4, vacc_day=5, first_infectee=6, next_sibling=7)   # word of each 32-bit field
-PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install')
+PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg')
+# exact cross-shard attribution (include/reina_hip.h): global ids = [shard : 4][index : 27]; the phases of a day and the
+# collectives reina_step_phase asks for
+GID_SHIFT = 27
+GID_INDEX_MASK = (1 << GID_SHIFT) - 1
+PH_OPEN, PH_TRACE, PH_MAIN, PH_END, PH_FEEDBACK, PH_NR = range(6)
+X_ALLREDUCE, X_ALLTOALL = 1, 2
 
 ABI_FUNCTIONS = ('create', 'destroy', 'bind_buffers', 'init_state', 'set_initial_state', 'upload_contact_tables',
-                 'step_day', 'step_day_begin', 'step_day_end', 'set_collective', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'read_history', 'profile_enable', 'profile_read',
+                 'step_day', 'step_day_begin', 'step_day_end', 'step_phase', 'set_collective', 'set_alltoall', 'run_days', 'run_days_hist', 'sample', 'read_counters', 'read_history', 'profile_enable', 'profile_read',
                  'profile_read_kernels',
                  'group_create', 'group_destroy', 'group_upload_contact_tables', 'group_run_days',
                  'build_contact_tables', 'test_prims', 'last_error', 'abi_version')
@@ -67,7 +74,9 @@ class Config(ctypes.Structure):
                 ('max_work_items', ctypes.c_uint32), ('max_candidates', ctypes.c_uint32),
                 ('max_queue', ctypes.c_uint32), ('n_shards', ctypes.c_uint32),
                 ('shard_rank', ctypes.c_uint32), ('mirror_slots', ctypes.c_uint32), ('hosp_ranges', ctypes.c_uint32),
-                ('age_start', ctypes.c_int32 * (MAX_AGES + 1))]
+                ('age_start', ctypes.c_int32 * (MAX_AGES + 1)),
+                ('exact_attribution', ctypes.c_uint32), ('xchg_cap', ctypes.c_uint32), ('pool_cap', ctypes.c_uint32),
+                ('reserved_', ctypes.c_uint32), ('shard_age_start', ctypes.c_void_p)]
 
 
 _FV = ctypes.c_float * MAX_VARIANTS
@@ -100,7 +109,7 @@ class ContactTablesABI(ctypes.Structure):
 
 BUFFER_FIELDS = ('hot', 'cold', 'infectees', 'counters', 'control', 'work_items', 'candidates',
                  'queue0', 'queue1', 'level1', 'hosp_events', 'pressure', 'mirror', 'mirror_meta', 'work_counts', 'scan_lists',
-                 'active_bits', 'infected_bits')
+                 'active_bits', 'infected_bits', 'xsend', 'xrecv', 'infectee_pool')
 
 
 class Buffers(ctypes.Structure):
@@ -176,6 +185,12 @@ def exchange_words(n_shards, ranges):
     return PRESSURE_WORDS + (n_shards * 2 * ranges if n_shards > 1 else 0)
 
 
+def xchg_words(n_shards, xchg_cap):
+    """include/reina_hip.h: REINA_XCHG_WORDS -- 64-bit words of buffers.xsend / xrecv (exact attribution): per peer shard a
+    count word and xchg_cap records"""
+    return n_shards * (xchg_cap + 1)
+
+
 def bind_abi(lib, prefix):
     """Resolve and type every ABI entry point; raises AttributeError if one is missing."""
     f = {}
@@ -191,7 +206,9 @@ def bind_abi(lib, prefix):
     f['step_day'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['step_day_begin'].argtypes = [vp, ctypes.POINTER(Day), vp]
     f['step_day_end'].argtypes = [vp, ctypes.POINTER(Day), vp]
+    f['step_phase'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_int, vp]
     f['set_collective'].argtypes = [vp, vp, vp]
+    f['set_alltoall'].argtypes = [vp, vp, vp]
     f['run_days'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp]
     f['run_days_hist'].argtypes = [vp, ctypes.POINTER(Day), ctypes.c_uint32, vp, vp]
     f['read_counters'].argtypes = [vp, vp, vp]
@@ -346,6 +363,11 @@ class Engine:
             # one bit per agent each: the hot word's ACTIVE flag again (what k_day streams on a sparse day) / ever infected
             # (what a contact looks its target up in)
             active_bits=a.zeros(bits_words(n), np.uint32), infected_bits=a.zeros(bits_words(n), np.uint32),
+            # exact cross-shard attribution: the records bound for / received from the other shards, and the overflow nodes
+            # of the infectee lists (otherwise placeholders: the library wants non-null pointers)
+            xsend=a.zeros(xchg_words(config.n_shards, config.xchg_cap) if config.exact_attribution else 2, np.uint64),
+            xrecv=a.zeros(xchg_words(config.n_shards, config.xchg_cap) if config.exact_attribution else 2, np.uint64),
+            infectee_pool=a.zeros(2 * config.pool_cap if config.exact_attribution else 2, np.uint32),
         )
         bufs = Buffers(**{k: a.ptr(v) for k, v in self.tensors.items()})
         self._check(self.f['bind_buffers'](self._h, ctypes.byref(bufs)), 'bind_buffers')
@@ -397,6 +419,18 @@ class Engine:
 
     def step_day(self, day):
         self._check(self.f['step_day'](self._h, ctypes.byref(day), self.alloc.stream()), 'step_day')
+
+    def step_phase(self, day, phase):
+        """one phase of a day (include/reina_hip.h: reina_step_phase); returns the collectives that must follow (X_*)"""
+        rc = self.f['step_phase'](self._h, ctypes.byref(day), int(phase), self.alloc.stream())
+        if rc < 0:
+            self._check(rc, 'step_phase')
+        self._prefetched = False
+        return rc
+
+    def set_alltoall(self, fn_ptr, comm_ptr):
+        """in-stream exchange of exact attribution: address of an ncclAllToAll-compatible function + its communicator"""
+        self._check(self.f['set_alltoall'](self._h, fn_ptr, comm_ptr), 'set_alltoall')
 
     def set_collective(self, fn_ptr, comm_ptr):
         """in-stream pressure all-reduce: address of an ncclAllReduce-compatible function + its communicator"""

@@ -45,6 +45,7 @@ PROBLEM_TO_STR = {
     6: 'Other failure', 7: 'Wrong state', 8: 'Contact probability failure', 9: 'Infectees mismatch',
     100: 'Work list overflow', 101: 'Candidate list overflow', 102: 'Testing queue overflow',
     103: 'Hospital event list overflow', 104: 'Day counter overflow', 105: 'Device synchronisation timeout',
+    106: 'Cross-shard exchange segment overflow', 107: 'Infectee list pool overflow',
 }
 # main.pyx:660-682: infectiousness by day relative to symptom onset (Luca et al. 2020)
 INFECTIOUSNESS_OVER_TIME = (
@@ -239,6 +240,12 @@ class Context:
         self.shard_rank = comm.rank if comm is not None else 0
         self.n_shards = comm.world if comm is not None else 1
         self._split = (lambda x: x) if self.n_shards == 1 else (lambda x: split_count(x, self.shard_rank, self.n_shards))
+        # cross-shard infector links: 'exact' (global ids, contact / feedback / tracing records exchanged
+        # through all-to-all segments -- the true infector as in the reference, main.pyx:219-233) or 'mirror' (stand-in
+        # infectors, one all-reduce per day; sharding.py).  The comm object says which; exact unless told otherwise.
+        self.attribution = getattr(comm, 'attribution', 'exact') if self.n_shards > 1 else 'none'
+        if self.attribution not in ('exact', 'mirror', 'none'):
+            raise ValueError("comm.attribution must be 'exact' or 'mirror'")
         population_params = dict(population_params)
         ipc = population_params.pop('initial_population_condition', None)
 
@@ -303,6 +310,25 @@ class Context:
         cfg.mirror_slots = slots
         for a in range(_eng.MAX_AGES + 1):
             cfg.age_start[a] = int(self.age_start[a])
+        if self.attribution == 'exact':
+            if total > _eng.GID_INDEX_MASK:
+                raise ValueError('exact cross-shard attribution holds fewer than 2^27 agents per shard')
+            cfg.exact_attribution = 1
+            # records per peer shard and exchange.  An exchange moves whole segments whatever they hold (the host cannot know the
+            # counts without waiting for the GPU), so the capacity is what the exchange costs: 2.4 x the need of the default
+            # scenario's peak day (cross-shard contacts that pass the whole transmission test: 0.65 % of a shard's agents, spread
+            # over the peers -- DESIGN section 6).  A day with more fails loudly (problem 106); comm.xchg_cap overrides.
+            cap = getattr(comm, 'xchg_cap', None)
+            cfg.xchg_cap = int(cap) if cap else max(2048, total // (64 * self.n_shards))
+            cfg.pool_cap = max(4096, total // 16)
+            # every shard's age_start: a source draws its target on the other shard and needs its age
+            tab = np.zeros((self.n_shards, _eng.MAX_AGES + 1), dtype=np.int32)
+            for r in range(self.n_shards):
+                cnt = split_population(self.global_age_counts, r, self.n_shards)
+                tab[r, 1:nr_ages + 1] = np.cumsum(cnt)
+                tab[r, nr_ages + 1:] = int(cnt.sum())
+            self._shard_age_start = np.ascontiguousarray(tab)
+            cfg.shard_age_start = self._shard_age_start.ctypes.data
         if engine_factory is None:
             self.engine = _eng.hip_engine(cfg, disease, device)
         else:
@@ -341,6 +367,8 @@ class Context:
         self._in_stream = self._direct is not None and (self.n_shards > 1 or self.always_collective)
         if self._in_stream:
             self.engine.set_collective(self._direct.fn_ptr, self._direct.comm_ptr)
+            if self.attribution == 'exact':
+                self.engine.set_alltoall(self._direct.a2a_ptr, self._direct.comm_ptr)
         # main.pyx:1780-1781: the initial condition is applied last, before any intervention exists
         if ipc is not None and ipc.has_initial_state():
             self._set_initial_state(ipc)
@@ -552,10 +580,14 @@ class Context:
         if self._in_stream or (self.n_shards == 1 and not self.always_collective):
             self.engine.step_day(d)
         else:
-            # the ONLY per-day collective: sum the cross-shard infection pressure (2048 int32)
-            self.engine.step_day_begin(d)
-            self.comm.all_reduce_sum(self.engine.tensors['pressure'])
-            self.engine.step_day_end(d)
+            # the day phase by phase, the collectives each phase asks for in between: one all-reduce (the cross-shard
+            # pressure block with the bed / ICU event maps), and under exact attribution the record exchanges
+            for ph in range(_eng.PH_NR):
+                need = self.engine.step_phase(d, ph)
+                if need & _eng.X_ALLREDUCE:
+                    self.comm.all_reduce_sum(self.engine.tensors['pressure'])
+                if need & _eng.X_ALLTOALL:
+                    self.comm.all_to_all(self.engine.tensors['xsend'], self.engine.tensors['xrecv'])
 
     def iterate(self):
         d, changed = self._build_day()

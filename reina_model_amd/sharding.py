@@ -10,7 +10,15 @@ shards, handed out in one global order (priority bucket, shard, priority, agent)
 maps that ride on the same all-reduce (csrc/k_remote.inc); import and vaccination
 quotas are partitioned 1/G per shard.
 
-Infector links across shards ("mirror attribution"): the true infector of a cross-shard infection
+Infector links across shards.  EXACT attribution (the default): every link
+field holds a global id (shard, index); a cross-shard contact is completed at its SOURCE (every shard's age_start table is
+global knowledge, so the source draws the target and knows its age) and travels as an 8-byte record to the target's shard,
+which claims the target under the source's own key; the shard of an infection returns (source, infectee) so that the
+source's count and infectee list are true the next morning; contact tracing sends (candidate, tracer) requests to the
+candidate's shard, one exchange per level.  The exchanges are fixed-capacity all-to-alls (RCCL: ncclAllToAll queued on the day
+stream) at the points reina_step_phase names.
+
+"Mirror attribution" (comm.attribution = 'mirror': no exchange but the one all-reduce): the true infector of a cross-shard infection
 lives on another shard and is never shipped.  Shards are statistically exchangeable, so an
 infection realised from incoming pressure in cell (range, variant) takes as its infector a LOCAL
 source that aimed an attempt of the same cell at another shard today (sampled through a
@@ -89,6 +97,8 @@ class DirectRccl:
             self.close()
             raise RuntimeError('ncclCommInitRank failed: %d' % rc if rc != 0 else 'ncclCommInitRank failed on another rank')
         self.fn_ptr = ctypes.cast(self.lib.ncclAllReduce, ctypes.c_void_p).value
+        # exact attribution's exchanges: RCCL's own all-to-all (grouped ncclSend / ncclRecv inside the library), same stream
+        self.a2a_ptr = ctypes.cast(self.lib.ncclAllToAll, ctypes.c_void_p).value
         self.comm_ptr = self.comm.value
 
     def count(self):
@@ -112,9 +122,10 @@ class TorchComm:
     With the nccl backend the per-day exchange bypasses torch (DirectRccl, REINA_DIRECT_RCCL=0 turns
     that off); counter reductions at export time keep using torch.distributed."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, attribution='exact'):
         import torch
         import torch.distributed as dist
+        self.attribution = attribution
         self.torch = torch
         self.dist = dist
         self.group = group
@@ -156,36 +167,68 @@ class TorchComm:
     def all_reduce_max(self, buf):
         self._all_reduce(buf, self.dist.ReduceOp.MAX)
 
+    def all_to_all(self, send, recv):
+        """segment d of every rank's `send` -> segment (sender's rank) of rank d's `recv` (exact attribution's record
+        exchanges when the engine does not queue them itself: gloo, or REINA_DIRECT_RCCL=0)"""
+        s, r = self._as_tensor(send), self._as_tensor(recv)
+        if s.dtype == self.torch.uint64:   # (host arrays of the CPU checker: gloo moves signed words)
+            s, r = s.view(self.torch.int64), r.view(self.torch.int64)
+        if self._nccl and not s.is_cuda:
+            dev = self.torch.device('cuda', self.torch.cuda.current_device())
+            ts, tr = s.to(dev), r.to(dev)
+            self.dist.all_to_all_single(tr, ts, group=self.group)
+            r.copy_(tr.cpu())
+        else:
+            self.dist.all_to_all_single(r, s, group=self.group)
+
 
 class InProcessComm:
     """All G shards live in ONE process and are stepped in lock-step by `step_shards_together`
     (tests; single-GPU emulation of a sharded run).  Collectives are plain sums over the members."""
 
-    def __init__(self, rank, world, members):
+    def __init__(self, rank, world, members, attribution='exact'):
         self.rank = rank
         self.world = world
         self.members = members  # shared list of Contexts, filled by the driver
+        self.attribution = attribution
 
 
-def step_shards_together(contexts):
-    """One day for G in-process shards: all first halves, pressure summed, all second halves."""
+def step_shards_together(contexts, pool=None):
+    """One day for G in-process shards, phase by phase (include/reina_hip.h: reina_step_phase): every shard runs the phase,
+    then the collectives the phase asked for are carried out between them -- the pressure blocks summed, the exchange
+    segments swapped.  `pool`: an executor whose map() runs the shards' phases side by side (host engines: the C calls
+    release the GIL)."""
+    from . import engine as eng
     days = []
     for c in contexts:
         d, changed = c._build_day()
         if changed:
             c._upload_tables()
-        c.engine.step_day_begin(d)
         days.append(d)
-    bufs = [c.engine.tensors['pressure'] for c in contexts]
-    host = [np.array(c.engine.alloc.to_host(b), dtype=np.int64) for c, b in zip(contexts, bufs)]
-    total = np.sum(host, axis=0).astype(np.int32)
-    for c, b in zip(contexts, bufs):
-        if isinstance(b, np.ndarray):
-            b[:] = total
-        else:
-            b.copy_(c.engine.alloc.torch.from_numpy(total).to(b.device))
-    for c, d in zip(contexts, days):
-        c.engine.step_day_end(d)
+    for ph in range(eng.PH_NR):
+        need = set((pool.map if pool is not None else map)(lambda cd: cd[0].engine.step_phase(cd[1], ph), list(zip(contexts, days))))
+        assert len(need) == 1, 'the shards disagree about the collectives of phase %d: %s' % (ph, need)
+        need = need.pop()
+        if need & eng.X_ALLREDUCE:
+            bufs = [c.engine.tensors['pressure'] for c in contexts]
+            host = [np.array(c.engine.alloc.to_host(b), dtype=np.int64) for c, b in zip(contexts, bufs)]
+            total = np.sum(host, axis=0).astype(np.int32)
+            for c, b in zip(contexts, bufs):
+                if isinstance(b, np.ndarray):
+                    b[:] = total
+                else:
+                    b.copy_(c.engine.alloc.torch.from_numpy(total).to(b.device))
+        if need & eng.X_ALLTOALL:
+            G = len(contexts)
+            send = [np.asarray(c.engine.alloc.to_host(c.engine.tensors['xsend'])).reshape(G, -1) for c in contexts]
+            for r, c in enumerate(contexts):
+                got = np.ascontiguousarray(np.stack([send[s][r] for s in range(G)]).reshape(-1))
+                b = c.engine.tensors['xrecv']
+                if isinstance(b, np.ndarray):
+                    b[:] = got.view(b.dtype)
+                else:
+                    b.copy_(c.engine.alloc.torch.from_numpy(got.view(np.int64)).to(b.device))
+    for c in contexts:
         c.day += 1
 
 

@@ -8,9 +8,9 @@ A scenario counts as a failure only if an independent second seed set confirms i
 have heavy-tailed outcomes, and one seed set of 250 runs has produced z = 5 there from an early fluctuation that the
 next three sets did not show.
 (Test infrastructure: it drives both oracles, so it lives under tests/; tests/test_par_vs_seq.py runs a few cases.)
-usage: python tests/diff_a_b.py [first_case] [n_cases] [n_seeds] [shards]   (shards > 1: oracle B split over that many
-in-process shards -- the beds and ICU units are ONE pool there too (the shards exchange per-bucket maps of the day's events),
-so every quantity is compared)"""
+usage: python tests/diff_a_b.py [first_case] [n_cases] [n_seeds] [shards] [attribution]   (shards > 1: oracle B split over
+that many in-process shards -- the beds and ICU units are ONE pool there too (the shards exchange per-bucket maps of the day's
+events), so every quantity is compared; attribution: exact (default) or mirror, reina_model_amd/sharding.py)"""
 import os
 import sys
 
@@ -29,6 +29,7 @@ POP13 = ['susceptible', 'vaccinated', 'infected', 'all_infected', 'detected', 'a
          'dead', 'recovered', 'non_hospital_deaths', 'new_infections']
 SCAL = ['available_icu_units', 'available_hospital_beds', 'r', 'exposed_per_day', 'ct_cases_per_day']
 Z_MAX = 4.5
+ATTRIBUTION = 'exact'   # cross-shard infector links of a sharded oracle B (reina_model_amd/sharding.py)
 
 
 PERTURB_FROM = 1000   # cases from here on also draw the disease parameters (the defaults could hide a parameter that a
@@ -106,7 +107,7 @@ class ShardedB:
         members = []
         self.ctxs = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=ivs, ipc=ipc, device='cpu',
                                              engine_factory=par_backend.par_engine_factory,
-                                             comm=sharding.InProcessComm(r, G, members)) for r in range(G)]
+                                             comm=sharding.InProcessComm(r, G, members, attribution=ATTRIBUTION)) for r in range(G)]
 
     def generate_state(self):
         return self.ctxs[0].state_from_counters(self.sh.reduce_counters(self.ctxs))
@@ -204,6 +205,8 @@ if __name__ == '__main__':
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 48
     G = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    if len(sys.argv) > 5:
+        ATTRIBUTION = sys.argv[5]
     bad = 0
     for case in range(first, first + cases):
         failed, r, r2 = confirmed_failure(case, n, shards=G)

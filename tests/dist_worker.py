@@ -64,8 +64,9 @@ def main():
     ages = datasets.scaled_population(total)
     factory = None if backend == 'nccl' else par_backend.par_engine_factory
     device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', rank)) if backend == 'nccl' else 'cpu'
-    comm = sharding.TorchComm()
-    comm.always_collective = True  # exercise begin / all-reduce / end even when world == 1
+    attribution = os.environ.get('REINA_TEST_ATTRIBUTION', 'exact')   # cross-shard infector links (sharding.py)
+    comm = sharding.TorchComm(attribution=attribution)
+    comm.always_collective = True  # exercise the phases and their collectives even when world == 1
     if rank == 0:
         print('direct_rccl=%s' % (comm.direct is not None), flush=True)
     ctx = simulation.make_context(v, age_counts=ages, seed=21, engine_factory=factory, device=device, comm=comm)
@@ -89,7 +90,7 @@ def main():
     if rank == 0:
         members = []
         ref = [simulation.make_context(v, age_counts=ages, seed=21, engine_factory=par_backend.par_engine_factory,
-                                       comm=sharding.InProcessComm(r, world, members)) for r in range(world)]
+                                       comm=sharding.InProcessComm(r, world, members, attribution=attribution)) for r in range(world)]
         A = eng.MAX_AGES
         for d in range(days):
             expect = sharding.reduce_counters(ref)
@@ -104,7 +105,7 @@ def main():
         tot = lambda name: hist[:, eng.C_NAMES.index(name) * A:(eng.C_NAMES.index(name) + 1) * A].sum(axis=1)
         assert np.all(tot('susceptible') + tot('infected') + tot('recovered') + tot('dead') == n)
         assert tot('all_infected')[-1] > 1000
-        print('DIST_OK world=%d days=%d all_infected=%d' % (world, days, tot('all_infected')[-1]), flush=True)
+        print('DIST_OK world=%d days=%d all_infected=%d attribution=%s' % (world, days, tot('all_infected')[-1], ctx.attribution), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

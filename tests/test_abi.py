@@ -29,13 +29,15 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), name
     f = eng.bind_abi(lib, 'reina_')
-    assert f["abi_version"]() == eng.ABI_VERSION == 4
+    assert f["abi_version"]() == eng.ABI_VERSION == 5
 
 
 def test_struct_layouts_match_the_header_sizes():
     # sizes computed from the header's field lists (all 4/8-byte naturally aligned members)
     A, V, E = eng.MAX_AGES, eng.MAX_VARIANTS, eng.MAX_ENTRIES
-    assert ctypes.sizeof(eng.Config) == 4 * 4 + 8 + 6 * 4 + 4 * (A + 1) + 4  # tail padding to 8
+    # (4 words, the 64-bit seed, 7 words, age_start, 4 words of exact attribution, the shard_age_start pointer)
+    assert ctypes.sizeof(eng.Config) == 4 * 4 + 8 + 7 * 4 + 4 * (A + 1) + 4 * 4 + 8
+    assert eng.Config.shard_age_start.offset % 8 == 0
     assert ctypes.sizeof(eng.Disease) == 4 * (11 * V + V * 24 + V * A + 5 * A + 1 + 3 * 16)
     assert ctypes.sizeof(eng.Buffers) == 8 * len(eng.BUFFER_FIELDS)
     assert ctypes.sizeof(eng.Day) == 8 * 4 + 16 * 16 + 16 * 16 + 8

@@ -28,13 +28,15 @@ def _launch(world, backend, days, total, timeout=600, extra_env=None, mode=None)
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize('world', [2, 3, 8])
-def test_gloo_sharded_run_equals_in_process_sharded_run(world):
+@pytest.mark.parametrize('world,attribution', [(2, 'exact'), (3, 'exact'), (8, 'exact'), (2, 'mirror'), (3, 'mirror')])
+def test_gloo_sharded_run_equals_in_process_sharded_run(world, attribution):
     """world 8 = the rank count of BASELINE configs[3] (one process per GPU of the node): eight ranks' pressure blocks
-    through one all-reduce per day, beds / ICU units / imports split eight ways"""
-    r = _launch(world, 'gloo', 100 if world < 8 else 70, 40000, timeout=900)
+    through one all-reduce per day, beds / ICU units / imports split eight ways.  exact: the contact, feedback and tracing
+    records through torch.distributed.all_to_all_single between the phases of every day (gloo == in-process)"""
+    r = _launch(world, 'gloo', 130 if world < 8 else 70, 40000, timeout=900, extra_env={'REINA_TEST_ATTRIBUTION': attribution})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'DIST_OK world=%d' % world in r.stdout
+    assert 'attribution=%s' % (attribution if world > 1 else 'none') in r.stdout
 
 
 def test_gloo_ensemble_is_partitioned_over_the_ranks():

@@ -56,31 +56,12 @@ def _assert_state_equal(gpu, cpu):
         qa = np.sort(gpu.engine.alloc.to_host(tg[q])[:cg[l]].view(np.uint32))
         qb = np.sort(np.asarray(tc[q])[:cc[l]].view(np.uint32))
         assert np.array_equal(qa, qb), q
-    # infectee lists: same sets per infector (insertion order is free) -- EVERY inline slot and EVERY overflow chain
+    # infectee lists: same sets per infector (insertion order is free) -- EVERY inline slot and EVERY overflow chain (threaded
+    # through the infectees' records, or through the pool's nodes under exact attribution: shard_util.list_pairs)
+    from shard_util import list_pairs
     fa = gpu.engine.alloc.to_host(tg['first_infectee'])
-    na = gpu.engine.alloc.to_host(tg['next_sibling'])
-    fb, nb = np.asarray(tc['first_infectee']), np.asarray(tc['next_sibling'])
     ia = gpu.engine.alloc.to_host(tg['infectees']).reshape(-1, eng.INLINE_INFECTEES)
-    ib = np.asarray(tc['infectees']).reshape(-1, eng.INLINE_INFECTEES)
-
-    def chain_pairs(inline, f, n):
-        """sorted (infector, infectee) pairs of all lists: the inline slots (-1 = empty) and the linked overflow list; a list
-        holds at most 64 entries (main.pyx:128)"""
-        o, k = np.nonzero(inline >= 0)
-        pairs = [o.astype(np.int64) * (1 << 32) + inline[o, k].astype(np.int64)]
-        owner = np.nonzero(f >= 0)[0].astype(np.int64)
-        cur = f[owner].astype(np.int64)
-        for _ in range(70):
-            if len(cur) == 0:
-                break
-            pairs.append(owner * (1 << 32) + cur)
-            nxt = n[cur].astype(np.int64)
-            keep = nxt >= 0
-            owner, cur = owner[keep], nxt[keep]
-        assert len(cur) == 0, 'an infectee list longer than 64 entries (or a cycle)'
-        return np.sort(np.concatenate(pairs))
-
-    pa, pb = chain_pairs(ia, fa, na), chain_pairs(ib, fb, nb)
+    pa, pb = list_pairs(gpu), list_pairs(cpu)
     assert np.array_equal(pa, pb), 'infectee lists'
     # an inline block is filled by rank: no hole before a used slot, and the overflow list starts only when it is full
     used = (ia >= 0).sum(axis=1)
@@ -333,19 +314,30 @@ def test_conservation_at_scale(total):
     assert np.array_equal(hist, again)
 
 
-def test_sharded_population_two_shards_on_one_gpu():
-    """SURVEY 8e: the population split over G=2 engine instances (both on this GPU, stepped in
-    lock-step with the pressure buffers summed in between) == the same on the CPU oracle."""
+def _sharded_pair(v, ages, seed, G, attribution='exact', interventions=None, ipc=None):
+    """G in-process shards on this GPU and the same on the CPU checker, cross-shard links `attribution` (sharding.py)"""
     import par_backend
+    from reina_model_amd import sharding
+    gm, cm = [], []
+    gpu = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=interventions, ipc=ipc,
+                                   comm=sharding.InProcessComm(r, G, gm, attribution=attribution)) for r in range(G)]
+    cpu = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=interventions, ipc=ipc,
+                                   comm=sharding.InProcessComm(r, G, cm, attribution=attribution),
+                                   engine_factory=par_backend.par_engine_factory) for r in range(G)]
+    return gpu, cpu
+
+
+@pytest.mark.parametrize('attribution', ['exact', 'mirror'])
+def test_sharded_population_two_shards_on_one_gpu(attribution):
+    """SURVEY 8e: the population split over G=2 engine instances (both on this GPU, stepped in
+    lock-step, phase by phase, with the collectives carried out in between) == the same on the CPU oracle.  exact: SURVEY 8
+    f-4 -- global ids, contact / feedback / tracing records through the all-to-all segments; mirror: stand-in infectors"""
     from reina_model_amd import sharding
     v = copy.deepcopy(VARIABLE_DEFAULTS)
     v.update(hospital_beds=30, icu_units=4)
     ages = datasets.scaled_population(60000)
     G = 2
-    gm, cm = [], []
-    gpu = [simulation.make_context(v, age_counts=ages, seed=4, comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
-    cpu = [simulation.make_context(v, age_counts=ages, seed=4, comm=sharding.InProcessComm(r, G, cm),
-                                   engine_factory=par_backend.par_engine_factory) for r in range(G)]
+    gpu, cpu = _sharded_pair(v, ages, 4, G, attribution)
     for d in range(160):
         sharding.step_shards_together(gpu)
         sharding.step_shards_together(cpu)
@@ -356,10 +348,15 @@ def test_sharded_population_two_shards_on_one_gpu():
         _assert_state_equal(a, b)
     tot = sharding.reduce_counters(gpu)
     assert tot[eng.C_NAMES.index('all_infected') * eng.MAX_AGES:][:101].sum() > 5000
+    if attribution == 'exact':
+        from shard_util import assert_links_are_true
+        info = assert_links_are_true(gpu)
+        assert info['cross_shard'] > 2000
 
 
+@pytest.mark.parametrize('attribution', ['exact', 'mirror'])
 @pytest.mark.parametrize('case', [155, 489, 703, 822, 1008, 2034, 2058, 200812, 7, 8, 9, 10, 11])
-def test_random_scenarios_on_two_to_four_shards(case):
+def test_random_scenarios_on_two_to_four_shards(case, attribution):
     """The sharded leg of the randomised soak (tools/parity_soak.py ... sharded) in the suite: random scenarios on 2-4
     in-process shards, HIP == oracle B on every tenth day's counters and on the final state.  The first seven are scenarios
     on which the soak of round 3 found mismatches that did not repeat run to run -- a stale stand-in infector (mirror
@@ -368,8 +365,9 @@ def test_random_scenarios_on_two_to_four_shards(case):
     oracle run_remote); 3200 further sharded scenarios then ran clean.  Case 200812 is the scenario on which a later soak found a
     HOLE in a source's inline infectee slots: a stand-in of TODAY that today's scan had removed (its list given up) took an
     infection count without a slot while a contact of the same morning took the next count with one -- a stand-in of any age
-    must be an agent that has not been removed."""
-    import par_backend
+    must be an agent that has not been removed.
+    Round 5: every case also under EXACT attribution (no stand-ins at all: the true infector's global id, the exchanges of
+    include/reina_hip.h) -- bit for bit against oracle B in that mode, and the links are checked to be the true ones."""
     from reina_model_amd import sharding
     rng = np.random.default_rng(300000 + case)
     v, ages, days, ivs, ipc = _random_scenario(rng)
@@ -377,10 +375,7 @@ def test_random_scenarios_on_two_to_four_shards(case):
     seed = int(rng.integers(0, 2 ** 31))
     if ipc is not None and v['hospital_beds'] == 0 and ipc.get('in_icu', 0) > 0:
         ipc = dict(ipc, in_icu=0)   # (refused by the reference and by both engines: tested elsewhere)
-    gm, cm = [], []
-    gpu = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=ivs, ipc=ipc, comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
-    cpu = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=ivs, ipc=ipc, comm=sharding.InProcessComm(r, G, cm),
-                                   engine_factory=par_backend.par_engine_factory) for r in range(G)]
+    gpu, cpu = _sharded_pair(v, ages, seed, G, attribution, ivs, ipc)
     for d in range(min(days, 100)):
         sharding.step_shards_together(gpu)
         sharding.step_shards_together(cpu)
@@ -390,6 +385,9 @@ def test_random_scenarios_on_two_to_four_shards(case):
     for a, b in zip(gpu, cpu):
         assert np.array_equal(a.engine.read_counters(), b.engine.read_counters())
         _assert_state_equal(a, b)
+    if attribution == 'exact' and not sharding.reduce_counters(gpu)[eng.C_NR * eng.MAX_AGES + eng.S_PROBLEM]:
+        from shard_util import assert_links_are_true
+        assert_links_are_true(gpu)
 
 
 def _random_scenario(rng):
@@ -902,10 +900,7 @@ def test_sharded_hundred_million_through_the_saturated_peak_against_oracle_b():
     from reina_model_amd import sharding
     G, days = 4, 110
     v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 100_000_000)
-    gm, cm = [], []
-    gpu = [simulation.make_context(v, age_counts=ages, seed=6, comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
-    cpu = [simulation.make_context(v, age_counts=ages, seed=6, comm=sharding.InProcessComm(r, G, cm),
-                                   engine_factory=par_backend.par_engine_factory) for r in range(G)]
+    gpu, cpu = _sharded_pair(v, ages, 6, G, 'mirror')
     for d in range(days):
         sharding.step_shards_together(gpu)
         sharding.step_shards_together(cpu)
@@ -936,47 +931,26 @@ def test_the_metrics_hundred_million_agents_against_oracle_b():
     assert peak > 20_000, peak
 
 
-def _step_cpu_shards_in_threads(contexts, pool):
-    """sharding.step_shards_together for shards of the CPU checker, the two halves of the day run by one thread per shard (the
-    C calls release the GIL): a year of 10^8 agents is minutes on one core"""
-    from reina_model_amd import sharding  # noqa: F401
-    days = []
-    for c in contexts:
-        d, changed = c._build_day()
-        if changed:
-            c._upload_tables()
-        days.append(d)
-    list(pool.map(lambda cd: cd[0].engine.step_day_begin(cd[1]), zip(contexts, days)))
-    bufs = [c.engine.tensors['pressure'] for c in contexts]
-    total = np.sum([np.asarray(b, dtype=np.int64) for b in bufs], axis=0).astype(np.int32)
-    for b in bufs:
-        b[:] = total
-    list(pool.map(lambda cd: cd[0].engine.step_day_end(cd[1]), zip(contexts, days)))
-    for c in contexts:
-        c.day += 1
-
-
-def test_north_stars_target_configuration_a_whole_year_on_eight_shards_against_oracle_b():
+@pytest.mark.parametrize('attribution', ['exact', 'mirror'])
+def test_north_stars_target_configuration_a_whole_year_on_eight_shards_against_oracle_b(attribution):
     """BASELINE.json's target configuration -- 10^8 agents over 8 GPUs -- as 8 in-process shards of 12.5 M agents on one GPU,
     ALL 365 days of the scaled default scenario: the first wave with the ONE pool of beds and ICU units saturated across
-    the shards, contact tracing at 30 % from day 118 under mirror attribution, the weekly imports from July on, the autumn
+    the shards, contact tracing at 30 % from day 118, the weekly imports from July on, the autumn
     wave and the b1.1.7 imports -- every shard's counter block every tenth day and the final per-agent state of every
     shard bit for bit against oracle B sharded the same way (round-3 verdict, item 3b: no sharded run at scale had been
-    stepped, let alone compared, beyond day 130)."""
+    stepped, let alone compared, beyond day 130).  Round 5 (verdict item 1): under EXACT attribution -- contact records,
+    feedback and, from day 118, two levels of tracing requests through the all-to-all segments, every link the true one --
+    and under mirror attribution as before.  (Oracle B's shards run their phases on a thread each.)"""
     import bench
-    import par_backend
     from concurrent.futures import ThreadPoolExecutor
     from reina_model_amd import sharding
     G, days = 8, 365
     v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 100_000_000)
-    gm, cm = [], []
-    gpu = [simulation.make_context(v, age_counts=ages, seed=9, comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
-    cpu = [simulation.make_context(v, age_counts=ages, seed=9, comm=sharding.InProcessComm(r, G, cm),
-                                   engine_factory=par_backend.par_engine_factory) for r in range(G)]
+    gpu, cpu = _sharded_pair(v, ages, 9, G, attribution)
     with ThreadPoolExecutor(G) as pool:
         for d in range(days):
             sharding.step_shards_together(gpu)
-            _step_cpu_shards_in_threads(cpu, pool)
+            sharding.step_shards_together(cpu, pool)
             if d % 10 == 9 or d == days - 1:
                 for a, b in zip(gpu, cpu):
                     assert np.array_equal(a.engine.read_counters(), b.engine.read_counters()), 'day %d' % d
@@ -989,6 +963,10 @@ def test_north_stars_target_configuration_a_whole_year_on_eight_shards_against_o
     for a, b in zip(gpu, cpu):
         _assert_state_equal(a, b)
         assert int(a.engine.read_counters()[eng.C_NR * A + eng.S_PROBLEM]) == 0
+    if attribution == 'exact':
+        from shard_util import assert_links_are_true
+        info = assert_links_are_true(gpu)
+        assert info['cross_shard'] > 10_000_000 and info['listed'] > 1_000_000
 
 
 def test_config5_per_gpu_batch_of_128_hus_members():
