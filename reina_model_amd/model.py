@@ -318,8 +318,10 @@ class Context:
             # counts without waiting for the GPU), so the capacity is what the exchange costs: 2.4 x the need of the default
             # scenario's peak day (cross-shard contacts that pass the whole transmission test: 0.65 % of a shard's agents, spread
             # over the peers -- DESIGN section 6).  A day with more fails loudly (problem 106); comm.xchg_cap overrides.
+            # (the same on every shard -- the segments are exchanged whole --: from the largest shard's size)
             cap = getattr(comm, 'xchg_cap', None)
-            cfg.xchg_cap = int(cap) if cap else max(2048, total // (64 * self.n_shards))
+            largest = int(sum(-(-int(c) // self.n_shards) for c in self.global_age_counts))
+            cfg.xchg_cap = int(cap) if cap else max(2048, largest // (64 * self.n_shards))
             cfg.pool_cap = max(4096, total // 16)
             # every shard's age_start: a source draws its target on the other shard and needs its age
             tab = np.zeros((self.n_shards, _eng.MAX_AGES + 1), dtype=np.int32)
