@@ -174,10 +174,16 @@ class TorchComm:
         if s.dtype == self.torch.uint64:   # (host arrays of the CPU checker: gloo moves signed words)
             s, r = s.view(self.torch.int64), r.view(self.torch.int64)
         if self._nccl and not s.is_cuda:
+            # RCCL moves device memory only: stage host buffers through HBM
             dev = self.torch.device('cuda', self.torch.cuda.current_device())
             ts, tr = s.to(dev), r.to(dev)
             self.dist.all_to_all_single(tr, ts, group=self.group)
             r.copy_(tr.cpu())
+        elif not self._nccl and s.is_cuda:
+            # gloo exchanges host memory: HBM buffers go through the host (two ranks sharing one GPU: a plumbing check)
+            ts, tr = s.cpu(), r.cpu()
+            self.dist.all_to_all_single(tr, ts, group=self.group)
+            r.copy_(tr.to(r.device))
         else:
             self.dist.all_to_all_single(r, s, group=self.group)
 

@@ -69,6 +69,23 @@ def main():
     comm.always_collective = True  # exercise the phases and their collectives even when world == 1
     if rank == 0:
         print('direct_rccl=%s' % (comm.direct is not None), flush=True)
+    if comm.direct is not None:
+        # the exchange of exact attribution as the engine queues it: RCCL's ncclAllToAll through the function pointer
+        # reina_set_alltoall receives (count per peer, ncclInt64 = 4), on the day stream, with this rank's own communicator --
+        # every rank's segment k must arrive as segment (rank) at rank k
+        import ctypes
+        n = 1000
+        send = (torch.arange(world * n, dtype=torch.int64, device='cuda') + 1000003 * rank)
+        recv = torch.zeros(world * n, dtype=torch.int64, device='cuda')
+        fn = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)(comm.direct.a2a_ptr)
+        rc = fn(send.data_ptr(), recv.data_ptr(), n, 4, comm.direct.comm_ptr, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0, rc
+        for k in range(world):
+            want = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64, device='cuda') + 1000003 * k
+            assert torch.equal(recv[k * n:(k + 1) * n], want), 'ncclAllToAll through the engine hook: segment %d' % k
+        if rank == 0:
+            print('direct_alltoall=ok', flush=True)
     ctx = simulation.make_context(v, age_counts=ages, seed=21, engine_factory=factory, device=device, comm=comm)
     if len(sys.argv) > 4 and sys.argv[4] == 'ensemble':
         # config 5 shape: seeds partitioned over the ranks, gathered on rank 0

@@ -78,6 +78,8 @@ def test_nccl_single_rank_exercises_the_collective_path():
     # ... and it went through the engine's in-stream collective (our own RCCL communicator,
     # ncclAllReduce queued on the day stream by reina_step_day)
     assert 'direct_rccl=True' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # ... and RCCL's all-to-all answered through the pointer reina_set_alltoall takes (exact attribution's in-stream exchange)
+    assert 'direct_alltoall=ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -876,17 +876,31 @@ def test_config3_at_full_size_eight_shards_of_fifty_million():
 
 
 def test_config2_fifty_million_agents_against_oracle_b():
-    """BASELINE configs[2] at its stated size (5 x 10^7 synthetic agents, one GPU): the first 130 days of the scaled default
+    """BASELINE configs[2] at its stated size (5 x 10^7 synthetic agents, one GPU): the first 250 days of the scaled default
     scenario -- through the peak of the first wave, with beds and ICU units saturated and the ordered event walk of a large
-    population on every one of those days -- per-day counter blocks and the final per-agent state bit for bit against
-    oracle B (about half a minute of CPU).  Round 2 had this as a hand-run one-off (tools/parity_50m.py)."""
+    population on every one of those days; contact tracing from day 118; from day 134 the WEEKLY IMPORTS placed beside the
+    stream by several import workgroups (k_open.inc: day_imports_block -- round 4's code, until now compared with the oracle
+    only at HUS size, at 9 M agents and sharded: round-4 verdict item 5a); the start of the autumn wave -- per-day counter
+    blocks and the final per-agent state bit for bit against oracle B (about a minute of CPU)."""
     import bench
     v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 50_000_000)
-    gpu, cpu = _run_and_compare(v, ages, 0, 130, chunk=65)
+    gpu, cpu = _run_and_compare(v, ages, 0, 250, chunk=125)
     c = gpu.per_age_counters()
     assert c['all_infected'].sum() > 5_000_000
     peak = int(gpu.engine.alloc.to_host(gpu.engine.tensors['control'])[eng.L_HOSP_PEAK])
     assert peak > 10_000, peak   # the ordered walk really ran on a day with tens of thousands of events
+
+
+def test_two_hundred_million_agents_against_oracle_b():
+    """SURVEY 8d's HBM-resident point, 2 x 10^8 agents unsharded -- the one size of the bench line that had no oracle
+    comparison at all (round-4 verdict item 5b): the first 40 days of the scaled default scenario (the imports scaled with
+    the population: hundreds of thousands infected by then), every day's counter block and the final per-agent state bit
+    for bit against oracle B."""
+    import bench
+    v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 200_000_000)
+    gpu, cpu = _run_and_compare(v, ages, 0, 40, chunk=20)
+    c = gpu.per_age_counters()
+    assert c['all_infected'].sum() > 100_000
 
 
 def test_sharded_hundred_million_through_the_saturated_peak_against_oracle_b():
