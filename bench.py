@@ -55,7 +55,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 HUS_AGENTS = 1685983
-DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install')
+DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg', 'collective')
+DAY_IMAGE_BYTES = 101 * 1024   # k_day's LDS image of the contact tables, staged once per workgroup (k_contacts.inc: DayShared + rows)
 
 
 def scaled_scenario(variables, total_agents):
@@ -77,14 +78,14 @@ def scaled_scenario(variables, total_agents):
     return v, datasets.scaled_population(total_agents)
 
 
-_COMM = []
+_COMM = {}
 
 
-def _shared_comm(sharding):
-    """one communicator (torch.distributed group + our RCCL communicator) for every run of this process"""
-    if not _COMM:
-        _COMM.append(sharding.TorchComm())
-    return _COMM[0]
+def _shared_comm(sharding, attribution='mirror'):
+    """one communicator (torch.distributed group + our RCCL communicator) per attribution mode for every run of this process"""
+    if attribution not in _COMM:
+        _COMM[attribution] = sharding.TorchComm(attribution=attribution)
+    return _COMM[attribution]
 
 
 def stride_for(steps, time_every):
@@ -94,12 +95,12 @@ def stride_for(steps, time_every):
     return 4 if steps < 64 else 8 if steps < 160 else 16
 
 
-def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=16, preheat_runs=2):
+def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=16, preheat_runs=2, attribution='mirror'):
     import numpy as np
     import torch
     from reina_model_amd import engine as eng
     from reina_model_amd import sharding, simulation
-    comm = _shared_comm(sharding) if dist is not None else None
+    comm = _shared_comm(sharding, attribution) if dist is not None else None
     for rep in range(preheat_runs if preheat else 0):
         # throw-away runs of the same workload (untimed, separate state): bring the GPU out of its
         # idle power state and pay one-time runtime costs before the measured simulation exists.
@@ -192,33 +193,42 @@ def src_sha256():
 
 
 def traffic_for(key):
-    """HBM bytes per day from the PMC passes, only if collected on this very binary"""
+    """PMC figures of profiles/traffic.json for configuration `key`, only if collected on this very binary (or on a build of
+    the very sources): (bytes per day, {kernel: bytes per day}, {kernel: utilisation figures}, note)"""
     try:
         tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
     except Exception:
-        return None, 'no profiles/traffic.json'
+        return None, {}, {}, 'no profiles/traffic.json'
     how = None
     if tj.get('lib_sha256') == lib_sha256():
         how = 'the binary being timed (sha256 match)'
     elif tj.get('src_sha256') and tj.get('src_sha256') == src_sha256():
         how = 'a build of the very sources this binary was built from (sha256 over csrc/ and include/ matches; the binary was rebuilt since)'
     if how is None:
-        return None, 'profiles/traffic.json was collected on another binary (sha256 %s..., commit %s) and other sources: not reported' % (
+        return None, {}, {}, 'profiles/traffic.json was collected on another binary (sha256 %s..., commit %s) and other sources: not reported' % (
             str(tj.get('lib_sha256'))[:12], tj.get('commit'))
     val = tj.get('per_day_bytes', {}).get(key)
-    return val, 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the kernels of a day, mean over the scenario; collected on %s; commit %s' % (how, tj.get('commit'))
+    strip = lambda d: {k.split('<')[0]: v for k, v in d.items()}
+    return (val, strip(tj.get('per_kernel_bytes_per_day', {}).get(key, {})), strip(tj.get('utilisation', {}).get(key, {})),
+            'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the kernels of a day, mean over the scenario; collected on %s; commit %s' % (how, tj.get('commit')))
 
 
 def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
-    """day-level roofline + every kernel's HIP-event time"""
+    """the day against HBM three ways -- priced at SURVEY 8d's algorithmic bytes (what a hot-word streamer must move), at the
+    bytes the PMC counters saw move, and at a restated byte model of the engine as built -- + every kernel's HIP-event time +
+    the VALU-issue utilisation of the two kernels that own the day"""
     st, prof = res['stats'], res['prof']
     ms_per_step = res['dt'] * 1000 / steps
+    day_s = ms_per_step * 1e-3
     day_bytes = 4.0 * n_agents + 4.0 * st['mean_infected'] + 4.0 * st['contacts_per_day'] + 12.0 * st['new_infections_per_day']
-    achieved = day_bytes / (ms_per_step * 1e-3) / 1e9
+    achieved = day_bytes / day_s / 1e9
     alg = {   # algorithmic bytes per launch of the kernels that own a term of B_alg
         'k_day': 4.0 * n_agents + 4.0 * st['infected_on_scan_days'] + 4.0 * st['contacts_on_scan_days'],
         'k_hosp_install': 12.0 * st['new_infections_per_day'],
     }
+    moved_day, moved_k, util, note = (None, {}, {}, None)
+    if traffic_key is not None:
+        moved_day, moved_k, util, note = traffic_for(traffic_key)
     kernels, ksum = {}, 0.0
     for k in DAY_KERNELS:
         ms, n = prof.get(k, (0.0, 0))
@@ -227,25 +237,59 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
         us = ms * 1000.0 / n
         ent = dict(avg_launch_us=round(us, 3), timed_launches=n)
         if k in alg:
+            # what a kernel that streamed every hot word would have to move, over this kernel's time: a ratio that EXCEEDS 1
+            # where the kernel reads less than that (a sparse day streams one bit per agent) -- not a fraction of anything
             ent['algorithmic_bytes_per_launch'] = round(alg[k], 1)
-            ent['achieved_GBs'] = round(alg[k] / (us * 1e-6) / 1e9, 2)
-            ent['frac_of_hbm_peak'] = round(alg[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+            ent['vs_hot_word_streamer'] = round(alg[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        if k in moved_k:
+            # bytes the kernel moved (PMC, mean per simulated day; the kernel runs once a day) over its mean launch time
+            ent['moved_bytes_per_launch'] = moved_k[k]
+            ent['moved_GBs'] = round(moved_k[k] / (us * 1e-6) / 1e9, 2)
+            ent['moved'] = round(moved_k[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        if k in util:
+            ent['valu'] = {'mean_day': util[k].get('valu_mean_day'), 'peak_day': util[k].get('valu_peak_day')}
+            ent['waiting'] = {'mean_day': util[k].get('waiting_mean_day'), 'peak_day': util[k].get('waiting_peak_day')}
         kernels[k] = ent
-    every_day = [k for k in ('k_open', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install', 'k_hosp_sort', 'k_hosp_walk') if k in kernels]
+    every_day = [k for k in ('k_open', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install', 'k_hosp_sort', 'k_hosp_walk', 'k_xchg') if k in kernels]
     ksum = sum(kernels[k]['avg_launch_us'] for k in every_day)
     for k in every_day:
         kernels[k]['share_of_kernel_time'] = round(kernels[k]['avg_launch_us'] / ksum, 4) if ksum else None
+    # the engine AS BUILT, restated in bytes: a sparse day streams the ACTIVE bit plane (N / 8), fetches one
+    # 32-byte sector per active agent's word, stages k_day's table image once per workgroup, looks up one sector of the infected
+    # plane per contact that can transmit (1 in 50), and an infection touches five sectors (target word, target record, the
+    # source's count, two plane words), read and written back
+    sparse = n_agents >= 8_000_000
+    model = ((n_agents / 8.0 if sparse else 4.0 * n_agents) + (32.0 if sparse else 4.0) * st['mean_infected'] + 256 * DAY_IMAGE_BYTES
+             + 32.0 * st['contacts_per_day'] / 50.0 + 2 * 5 * 32.0 * st['new_infections_per_day'])
     out = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5),
-               traffic=None, scope='whole day: sum of B_alg over the timed days / wall time of the timed region (SURVEY.md 8d)',
+               traffic=moved_day, scope='whole day: sum of B_alg over the timed days / wall time of the timed region (SURVEY.md 8d)',
                algorithmic_bytes_per_day=round(day_bytes, 1),
                algorithmic_bytes_formula='4*N + 4*N_infected + 4*contacts + 12*new_infections (per day, means over the timed days)',
+               frac_meaning='vs_hot_word_streamer: the day priced at the bytes a kernel that read every agent\'s hot word would move. The engine '
+                            'does not (sparse days stream one bit per agent): `moved` is the measured figure',
+               moved=None, model_bytes_per_day=round(model, 1),
+               model_formula=('N/8 + 32*N_infected' if sparse else '4*N + 4*N_infected') + ' + 256 workgroups * table image + 32*contacts/50 + 320*new_infections',
+               wasted=None,
                ms_per_step=round(ms_per_step, 6), kernel_us_per_day=round(ksum, 3), kernels=kernels,
                kernel_timing='HIP events (start/stop of the dispatch packet, launch stream) inside the timed region; on a profiled day '
                              'one kind of kernel is timed: stride %d days per kind' % stride)
+    if moved_day:
+        # `moved`: HBM bytes per day from the PMC counters / the day's wall time / peak -- north_star's "achieved HBM GB/s against the
+        # chip's peak" read literally; `wasted`: moved bytes over the restated model's (sector granularity included)
+        out['moved'] = dict(bytes_per_day=moved_day, GBs=round(moved_day / day_s / 1e9, 2), frac=round(moved_day / day_s / 1e9 / HBM_PEAK_GBS, 5))
+        out['wasted'] = round(moved_day / model, 3)
+    if traffic_key is not None:
+        out['traffic_note'] = note
+    # what bounds the day (the SQ passes of profiles/r05_sq_*.csv): not HBM bandwidth in either regime
+    vd = (util.get('k_day') or {})
+    out['valu'] = {k: kernels[k]['valu'] for k in ('k_day', 'k_hosp_install') if k in kernels and 'valu' in kernels[k]} or None
+    out['bound_by_regime'] = {
+        'quiet_day': 'latency: three to four launches of dependent round trips at the dispatch floor (a 12.5 MB bit plane that HBM moves in 1.6 us)',
+        'peak_day': 'valu issue in k_day (contact sampling: Philox + table search per contact)' + (
+            ', %.2f of the chip\'s VALU issue slots over the launch' % vd['valu_peak_day'] if vd.get('valu_peak_day') else '') +
+            '; scattered-access latency in k_hosp_install'}
     if 'k_day' in kernels:
         out['dominant_kernel'] = dict(name='k_day', **kernels['k_day'])
-    if traffic_key is not None:
-        out['traffic'], out['traffic_note'] = traffic_for(traffic_key)
     return out
 
 
@@ -431,6 +475,10 @@ def main():
     ap.add_argument('--strong-agents', type=int, default=100_000_000,
                     help='N > 1: TOTAL agents of the `strong` object (north_star\'s target configuration: 10^8 agents over the ranks)')
     ap.add_argument('--no-strong', action='store_true')
+    ap.add_argument('--attribution', default='mirror', choices=('mirror', 'exact'),
+                    help='N > 1: cross-shard infector links of the headline, `large` and `strong` runs -- mirror: stand-in infectors, ONE '
+                         'all-reduce per day (north_star\'s exchange); exact: true links, three to five exchanges per day (SURVEY 8 f-4). '
+                         '`strong` carries the other mode\'s figure beside it')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-sizes', action='store_true', help='skip the full_scenario object')
     ap.add_argument('--no-large', action='store_true')
@@ -498,7 +546,7 @@ def main():
         workload = 'HUS %d agents (BASELINE configs[1]), default scenario (variables.py:227-435), days %d..%d' % (
             HUS_AGENTS, a.warmup, a.warmup + a.steps - 1)
         # (profiles/traffic.json holds the 365-day scenario's mean bytes per day: a shorter window gets no traffic figure)
-        traffic_key = 'hus' if a.steps == 365 else None
+        traffic_key = 'hus' if a.steps == 365 else 'hus_window' if (a.steps, a.warmup) == (20, 5) else None
 
     def max_over_ranks(dt):
         if world == 1:
@@ -507,7 +555,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    res = run_gpu(v, ages, a.seed, a.steps, a.warmup, device, dist, preheat=a.preheat_days, stride=stride)
+    res = run_gpu(v, ages, a.seed, a.steps, a.warmup, device, dist, preheat=a.preheat_days, stride=stride, attribution=a.attribution)
     res['dt'] = max_over_ranks(res['dt'])
     total_agents = int(np.asarray(ages).sum())
     n_agents = total_agents // world   # agents one k_day launch streams on this rank
@@ -517,7 +565,7 @@ def main():
     if world > 1 and not a.no_large and not a.agents:
         # BASELINE configs[3] shape on the same ranks: 50 M agents per GPU (4 x 10^8 on 8), sharded, full scenario
         vl, agesl = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.large_agents * world)
-        rl = run_gpu(vl, agesl, a.seed, 365, 0, device, dist, preheat=60, stride=16, preheat_runs=1)
+        rl = run_gpu(vl, agesl, a.seed, 365, 0, device, dist, preheat=60, stride=16, preheat_runs=1, attribution=a.attribution)
         rl['dt'] = max_over_ranks(rl['dt'])
         tot_l = int(np.asarray(agesl).sum())
         large_sharded = {
@@ -530,15 +578,30 @@ def main():
         # north_star's target configuration: 10^8 agents in TOTAL over the ranks -- strong scaling of the metric's size
         # (the N = 1 counterpart is full_scenario["100000000"] of the single-GPU line)
         vs_, ages_s = scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), a.strong_agents)
-        rs = run_gpu(vs_, ages_s, a.seed, 365, 0, device, dist, preheat=60, stride=16, preheat_runs=1)
+        rs = run_gpu(vs_, ages_s, a.seed, 365, 0, device, dist, preheat=60, stride=16, preheat_runs=1, attribution=a.attribution)
         rs['dt'] = max_over_ranks(rs['dt'])
         tot_s = int(np.asarray(ages_s).sum())
         strong_sharded = {
             'workload': 'synthetic %d agents in total (%d per GPU), default scenario scaled, 365 days' % (tot_s, tot_s // world),
-            'scaling': 'strong', 'value': round(tot_s * 365 / rs['dt'], 1), 'unit': 'agent-days/s',
+            'scaling': 'strong', 'attribution': a.attribution, 'value': round(tot_s * 365 / rs['dt'], 1), 'unit': 'agent-days/s',
             'ms_per_step': round(rs['dt'] * 1000 / 365, 6), 'rccl_world': rs['rccl_world'],
             'roofline': roofline_obj(tot_s // world, rs, 365, 16), 'final_all_infected': rs['stats']['final_all_infected'],
+            'expect': 'strong scaling of 10^8 agents is NEGATIVE on quiet days: a shard of 1.25 x 10^7 spends 67-86 us of kernels on a quiet '
+                      'day (two more launches, the cross-shard branches; profiles/r05_evidence/sharded_day_kernels.txt) plus the collectives\' '
+                      'latency, against 51 us for the whole 10^8 on one GPU; only the peak days gain (137-142 us per shard against 340). '
+                      'Sharding buys capacity (4 x 10^8 agents), not speed, at these sizes.  roofline.kernels: k_remote / k_hosp_sort are '
+                      'the launches sharding adds, `collective` is the event-timed cost of RCCL itself per exchange point',
         }
+        # the other attribution mode on the same ranks (exact: the true links, contact / feedback / tracing records through
+        # ncclAllToAll -- three to five exchanges a day instead of one)
+        other = 'exact' if a.attribution == 'mirror' else 'mirror'
+        try:
+            ro = run_gpu(vs_, ages_s, a.seed, 365, 0, device, dist, preheat=0, stride=16, preheat_runs=0, attribution=other)
+            ro['dt'] = max_over_ranks(ro['dt'])
+            strong_sharded[other] = {'value': round(tot_s * 365 / ro['dt'], 1), 'ms_per_step': round(ro['dt'] * 1000 / 365, 6),
+                                     'kernels': {k: round(ms * 1000 / c, 2) for k, (ms, c) in ro['prof'].items() if c}}
+        except Exception as e:   # noqa: BLE001 -- reported in the line itself
+            strong_sharded[other] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     ens_dist = None
     if world > 1 and not a.no_ensemble and not a.agents:
         try:
@@ -553,7 +616,9 @@ def main():
             'ms_per_step': round(res['dt'] * 1000 / a.steps, 6), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
             'config': {'workload': workload, 'agents_total': total_agents,
-                       'parallelism': 'single GPU' if world == 1 else 'agents sharded x%d, one RCCL all-reduce per day (infection pressure + the shards\' bed / ICU event maps)' % world,
+                       'parallelism': 'single GPU' if world == 1 else (
+                           'agents sharded x%d, one RCCL all-reduce per day (infection pressure + the shards\' bed / ICU event maps)' % world if a.attribution == 'mirror' else
+                           'agents sharded x%d, exact attribution: one RCCL all-reduce + two ncclAllToAll per day (four on contact-tracing days)' % world),
                        'final_all_infected': res['stats']['final_all_infected'], 'peak_infected_in_window': res['stats']['peak_infected']},
             'roofline': roofline_obj(n_agents, res, a.steps, stride, traffic_key),
             'notes': ['the timed region covers host planning, launches, every kernel of the days and the read-back of their history rows; '
@@ -564,9 +629,11 @@ def main():
                       'roofline.achieved / frac price the day at its ALGORITHMIC bytes (SURVEY 8d: every agent\'s 4-byte hot word once a '
                       'day, ...).  Since round 4 a population of >= 4 tiles per wave (about 8 M agents on a whole chip) does not read them: '
                       'k_day streams one ACTIVE bit per agent and fetches the words of the agents whose bit is set (the reference leaves '
-                      'everybody who is not infected at once too, main.pyx:1974-1975), so the HBM bytes actually moved -- roofline.traffic, '
-                      'PMC counters -- are about half the algorithmic ones at 5e7-2e8 agents, and a frac near or above 1 on a quiet day '
-                      'means "faster than a perfect stream of the hot words would be", not a measurement error'],
+                      'everybody who is not infected at once too, main.pyx:1974-1975), so the HBM bytes actually moved are about half the '
+                      'algorithmic ones at 5e7-2e8 agents.  roofline.moved is the measured figure (PMC bytes / wall time / 8 TB/s: north_star\'s '
+                      '"achieved HBM GB/s against the chip\'s peak"), roofline.wasted prices it against a restated byte model of the engine as '
+                      'built, roofline.valu / bound_by_regime say what bounds the day now: latency on quiet days, VALU issue on peak days -- '
+                      'not HBM bandwidth.  A kernel\'s vs_hot_word_streamer may exceed 1: it is a comparison with a streamer, not a fraction'],
         }
         if world > 1:
             out['notes'].append(

@@ -93,7 +93,7 @@ static bool kind_timed(int today, int kind) {
     if (today < 0) return false;
     if (today == REINA_PK_NR || today == kind) return true;
     // kernels that do not run every day are timed on k_open's days
-    if (today == REINA_PK_HOSPITAL && (kind == REINA_PK_REMOTE || kind == REINA_PK_HOSP_SORT || kind == REINA_PK_HOSP_WALK || kind == REINA_PK_XCHG)) return true;
+    if (today == REINA_PK_HOSPITAL && (kind == REINA_PK_REMOTE || kind == REINA_PK_HOSP_SORT || kind == REINA_PK_HOSP_WALK || kind == REINA_PK_XCHG || kind == REINA_PK_COLLECTIVE)) return true;
     return today == REINA_PK_OPEN && (kind == REINA_PK_TRACE1 || kind == REINA_PK_VACCINATE);
 }
 
@@ -752,19 +752,42 @@ static int launch_day_main(reina_engine_t *e, const MemberRef *refs, uint32_t K,
     // a vaccination programme: its pass over the agents comes after the test queue and before the stream
     // (HealthcareSystem.iterate, main.pyx:514-558)
     if (dp.n_vaccinations) {
-        // ONE programme whose number of the day exceeds a step of 16 x 1024 agents, a single engine: a chain of workgroups, one
-        // step each, with room for a third more agents than the number (k_open.inc: pro_vaccinate_chain); otherwise one workgroup
-        // (the number as the kernel clips it: a programme whose window holds fewer agents never needs the chain)
-        uint32_t vg = 1;
-        const reina_vaccination_t &v0 = dp.vaccinations[0];
-        const uint32_t window = v0.idx_end > v0.idx_start ? v0.idx_end - v0.idx_start : 0u;
-        const uint32_t nr0 = v0.nr < window ? v0.nr : window;
-        if (K == 1 && dp.n_vaccinations == 1 && nr0 > VACC_CHUNKS * PRO_THREADS && e->cfg.max_work_items >= 4096 && !e->vacc_one_wg) {
-            vg = (nr0 + nr0 / 3u) / (VACC_CHUNKS * PRO_THREADS) + 1u;
-            if (vg > e->n_cus) vg = e->n_cus;
-            if (vg > 256u) vg = 256u;
+        // a day on which some programme's number exceeds a step of 16 x 1024 agents: a chain of workgroups, one step each, with room
+        // for a third more agents than the largest number (k_open.inc: pro_vaccinate_chain; the programmes one after the other, the
+        // launch agreeing on each one's end); otherwise one workgroup.  (the numbers as the kernel clips them: a programme whose window
+        // holds fewer agents never needs the chain.)  Members of a group chain too while the whole launch stays resident.
+        uint32_t vg = 1, most = 0, need[REINA_MAX_VACCINATIONS], sum_need = 0;
+        bool disjoint = dp.n_vaccinations > 1;
+        for (uint32_t k = 0; k < dp.n_vaccinations; k++) {
+            const reina_vaccination_t &vk = dp.vaccinations[k];
+            const uint32_t window = vk.idx_end > vk.idx_start ? vk.idx_end - vk.idx_start : 0u;
+            const uint32_t nrk = vk.nr < window ? vk.nr : window;
+            if (nrk > most) most = nrk;
+            need[k] = (nrk + nrk / 3u) / (VACC_CHUNKS * PRO_THREADS) + 1u;
+            sum_need += need[k];
+            for (uint32_t j = 0; j < k; j++)
+                if (vk.idx_start < dp.vaccinations[j].idx_end && dp.vaccinations[j].idx_start < vk.idx_end) disjoint = false;
         }
-        LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(vg, K), dim3(PRO_THREADS), 0, s, dp);
+        VaccGeom geo;
+        std::memset(&geo, 0, sizeof(geo));
+        // (the published words live in the head of buffers.scan_lists: 16 programmes x 512 + 16 arrival words, 64 bits each)
+        if (most > VACC_CHUNKS * PRO_THREADS && e->cfg.max_work_items >= 8192 + 16 && !e->vacc_one_wg) {
+            uint32_t cap = K > 1 ? e->n_cus / K : e->n_cus;
+            if (cap > 256u) cap = 256u;
+            if (disjoint && sum_need <= cap) {
+                // age tiers side by side (windows pairwise disjoint: the order of the programmes does not matter): every
+                // programme on workgroups of its own, all at once
+                geo.parallel = 1u;
+                for (uint32_t k = 0; k < dp.n_vaccinations; k++) geo.g[k] = (uint16_t)need[k];
+                vg = sum_need;
+            } else {
+                vg = (most + most / 3u) / (VACC_CHUNKS * PRO_THREADS) + 1u;
+                if (vg > cap) vg = cap;
+            }
+            if (vg < 1u) vg = 1u;
+        }
+        if (++e->vacc_seq == 0u) e->vacc_seq = 1u;
+        LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(vg, K), dim3(PRO_THREADS), 0, s, dp, e->vacc_seq, geo);
     }
     LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks + stream_imports, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows,
                e->day_sparse_below, e->day_flags, stream_imports);
@@ -904,7 +927,11 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
     for (int ph = 0; ph < REINA_PH_NR; ph++) {
         const int need = reina_step_phase(e, day, ph, stream);
         if (need < 0) return need;
-        // the exchanges of a sharded population, queued on the day stream itself
+        // the exchanges of a sharded population, queued on the day stream itself (on the profiled days of the event-walk kind an
+        // event pair is recorded around them: `collective` of reina_profile_read_kernels -- what RCCL costs a day, apart from the kernels)
+        size_t ev_a = 0, ev_b = 0;
+        const bool timed = need > 0 && (e->coll_fn || e->a2a_fn) && kind_timed(profiled_kind(e, day->day), REINA_PK_COLLECTIVE) &&
+                           take_event_pair(e, &ev_a, &ev_b) && hipEventRecord(e->ev_pool[ev_a], (hipStream_t)stream) == hipSuccess;
         if ((need & REINA_X_ALLREDUCE) && e->coll_fn) {
             const int r = e->coll_fn(e->buf.pressure, e->buf.pressure, e->exchange_words, 2 /* ncclInt32 */, 0 /* ncclSum */, e->coll_comm, stream);
             if (r != 0) {
@@ -923,6 +950,7 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
                 return REINA_E_HIP;
             }
         }
+        if (timed && hipEventRecord(e->ev_pool[ev_b], (hipStream_t)stream) == hipSuccess) e->kpairs[REINA_PK_COLLECTIVE].emplace_back(ev_a, ev_b);
     }
     return REINA_OK;
 }

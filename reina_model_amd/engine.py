@@ -50,7 +50,7 @@ ABI_VERSION = 5   # reina_abi_version(): struct layouts of include/reina_hip.h (
 INLINE_INFECTEES = 8   # REINA_INLINE_INFECTEES
 COLD_WORDS = 8         # sizeof(reina_cold_t) / 4: claim (2 words), infector, n_infected, onset_days, vacc_day, first_infectee, next_sibling
 COLD_FIELDS = dict(infector=2, n_infected=3, onset_days=4, vacc_day=5, first_infectee=6, next_sibling=7)   # word of each 32-bit field
-PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg')
+PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg', 'collective')
 # exact cross-shard attribution (include/reina_hip.h): global ids = [shard : 4][index : 27]; the phases of a day and the
 # collectives reina_step_phase asks for
 GID_SHIFT = 27

@@ -17,7 +17,11 @@ for cfg in "hus:" "50m:--agents 50000000" "100m:--agents 100000000" "200m:--agen
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch_$name -- python3 $R/bench.py $COMMON $args > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write_$name -- python3 $R/bench.py $COMMON $args > /dev/null 2>&1
 done
-for cfg in "hus:" "100m:--agents 100000000"; do
+# the driver's window (bench.py's defaults there: --steps 20 --warmup 5) has its own traffic figure: all quiet days
+W="--no-cpu --no-sizes --no-ensemble --steps 20 --warmup 5 --preheat-days 0"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch_husw -- python3 $R/bench.py $W > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write_husw -- python3 $R/bench.py $W > /dev/null 2>&1
+for cfg in "hus:" "50m:--agents 50000000" "100m:--agents 100000000" "200m:--agents 200000000"; do
   name=${cfg%%:*}; args=${cfg#*:}
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/${TAG}_sq1_$name -- python3 $R/bench.py $COMMON $args > /dev/null 2>&1
   rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/${TAG}_sq2_$name -- python3 $R/bench.py $COMMON $args > /dev/null 2>&1

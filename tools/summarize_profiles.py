@@ -48,7 +48,10 @@ def day_kernel(n):
 
 per_day = {}
 per_kernel = {}
-for cfg, key in (('hus', 'hus'), ('50m', '50000000'), ('100m', '100000000'), ('200m', '200000000')):
+util = {}
+N_SIMD, CLOCK_GHZ = 1024, 2.4   # MI355X: 256 CUs x 4 SIMDs; the shader clock the cycle figures are priced at
+for cfg, key in (('hus', 'hus'), ('husw', 'hus_window'), ('50m', '50000000'), ('100m', '100000000'), ('200m', '200000000')):
+    DAYS = 25 if cfg == 'husw' else 365   # (husw: the driver's window, 5 untimed + 20 timed days -- all of them quiet, all counted)
     st = newest(os.path.join(G, '%s_trace_%s' % (tag, cfg), '*', '*kernel_stats.csv'))
     if st:
         shutil.copy(st[0], os.path.join(P, '%s_kernel_stats_%s.csv' % (tag, cfg)))
@@ -96,6 +99,7 @@ for cfg, key in (('hus', 'hus'), ('50m', '50000000'), ('100m', '100000000'), ('2
         with open(os.path.join(P, '%s_pmc_hbm_%s.csv' % (tag, cfg)), 'w') as f:
             csv.writer(f).writerows(rows)
     sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    disp = collections.defaultdict(dict)   # (pass, kernel) -> dispatch id -> {counter: value, 'ns': duration of THAT launch}
     for p in ('sq1', 'sq2', 'sq3'):
         f = newest(os.path.join(G, '%s_%s_%s' % (tag, p, cfg), '*', '*counter_collection.csv'))
         if f:
@@ -103,6 +107,32 @@ for cfg, key in (('hus', 'hus'), ('50m', '50000000'), ('100m', '100000000'), ('2
                 n = kname(r['Kernel_Name'])
                 if day_kernel(n):
                     sq[n][r['Counter_Name']].append(float(r['Counter_Value']))
+                    d = disp[(p, n)].setdefault(r['Dispatch_Id'], {})
+                    d[r['Counter_Name']] = float(r['Counter_Value'])
+                    d['ns'] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    # VALU issue utilisation of a launch = SQ_ACTIVE_INST_VALU (units of 4 clocks, summed over the chip) x 4 / (SIMDs x the launch's
+    # cycles at the shader clock); waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES -- counters and duration of the SAME launch of the same
+    # pass; "mean day": the sums over the year's launches, "peak day": the longest launch
+    u = {}
+    for n in sorted(set(k[1] for k in disp)):
+        ent = {}
+        d2 = [x for x in disp.get(('sq2', n), {}).values() if 'SQ_ACTIVE_INST_VALU' in x and x['ns'] > 0]
+        if d2:
+            pk = max(d2, key=lambda x: x['ns'])
+            ent['valu_mean_day'] = round(sum(x['SQ_ACTIVE_INST_VALU'] for x in d2) * 4 / (N_SIMD * sum(x['ns'] for x in d2) * CLOCK_GHZ), 4)
+            ent['valu_peak_day'] = round(pk['SQ_ACTIVE_INST_VALU'] * 4 / (N_SIMD * pk['ns'] * CLOCK_GHZ), 4)
+            ent['peak_launch_us_under_counters'] = round(pk['ns'] / 1000, 1)
+        d1 = [x for x in disp.get(('sq1', n), {}).values() if x.get('SQ_WAVE_CYCLES', 0) > 0 and 'SQ_WAIT_ANY' in x]
+        if d1:
+            pk = max(d1, key=lambda x: x['ns'])
+            ent['waiting_mean_day'] = round(sum(x['SQ_WAIT_ANY'] for x in d1) / sum(x['SQ_WAVE_CYCLES'] for x in d1), 4)
+            ent['waiting_peak_day'] = round(pk['SQ_WAIT_ANY'] / pk['SQ_WAVE_CYCLES'], 4)
+            if all('SQ_INSTS_SALU' in x and x.get('SQ_INSTS_VALU', 0) > 0 for x in d1):
+                ent['salu_per_valu_peak_day'] = round(pk['SQ_INSTS_SALU'] / pk['SQ_INSTS_VALU'], 4)
+        if ent:
+            u[n] = ent
+    if u:
+        util[key] = u
     if sq:
         with open(os.path.join(P, '%s_sq_%s.csv' % (tag, cfg), ), 'w') as f:
             w = csv.writer(f)
@@ -121,7 +151,9 @@ if per_day and os.path.exists(sha_f):
     sys.path.insert(0, ROOT)
     import bench as _bench
     json.dump({'lib_sha256': open(sha_f).read().strip(), 'src_sha256': _bench.src_sha256(), 'commit': commit, 'tag': tag, 'per_day_bytes': per_day,
-               'per_kernel_bytes_per_day': per_kernel,
+               'per_kernel_bytes_per_day': per_kernel, 'utilisation': util,
+               '_utilisation': 'per kernel, from the SQ passes of the same binary: valu = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch cycles at '
+                               '2.4 GHz), waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES; mean day = sums over the 365 launches, peak day = the longest launch',
                '_comment': 'HBM bytes per simulated day summed over every kernel of the day: rocprofv3 --pmc FETCH_SIZE and '
                            '--pmc WRITE_SIZE (separate passes, --kernel-trace only) over one 365-day scenario; FETCH_SIZE (KB) '
                            'doubled per MI355X_MICROARCH.md; raw per kernel in %s_pmc_hbm_<cfg>.csv' % tag},
