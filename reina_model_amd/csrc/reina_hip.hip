@@ -20,6 +20,13 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+// gfx950 (MI355X / CDNA4) only: k_day's hand-written ISA (global_load_dwordx4 into hand-reserved VGPRs, global_load_lds_dword through
+// M0, manual vmcnt accounting) and reina_prims.h's v_bitop3 Philox are written for this target and checked on it alone
+// (tests/test_abi.py disassembles the code object); another --offload-arch must not build silently
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libreina_hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 #include <climits>
 #include <cstddef>
 #include <cstdio>

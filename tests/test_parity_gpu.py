@@ -763,6 +763,29 @@ def test_a_vaccination_day_in_an_engine_group_runs_on_the_chain():
         _assert_state_equal(members[m], cpu)
 
 
+def test_weekly_imports_of_a_caller_with_a_tight_candidate_buffer():
+    """the weekly imports placed beside the stream leave their records in the shared candidate OVERFLOW
+    list; a caller of the C ABI that sizes max_candidates tightly (here: no room at all above the per-wave regions) has no such
+    list -- every weekly-import day then failed with CANDIDATE_OVERFLOW and dropped the imports.  The launch now places them in
+    the day's opening whenever they do not fit with room to spare: same days as oracle B, no problem flag."""
+    import par_backend
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    ivs = [['import-infections', '2020-02-19', 30], ['import-infections-weekly', '2020-02-22', 700, 40]]
+    ages = datasets.scaled_population(300000)
+
+    def tight(factory):
+        def make(cfg, dis):
+            cfg.max_candidates = cfg.max_work_items   # (the per-wave regions and nothing else)
+            return factory(cfg, dis)
+        return make
+    gpu = simulation.make_context(v, age_counts=ages, seed=5, interventions=ivs, engine_factory=tight(lambda c, d: eng.hip_engine(c, d)))
+    cpu = simulation.make_context(v, age_counts=ages, seed=5, interventions=ivs, engine_factory=tight(par_backend.par_engine_factory))
+    hg, hc = gpu.run(40), cpu.run(40)
+    assert np.array_equal(hg, hc)
+    _assert_state_equal(gpu, cpu)
+    assert gpu.per_age_counters()['all_infected'].sum() > 500
+
+
 def test_three_variants():
     """wild type + two variants with their own multipliers and durations, imported by date and through
     the weekly shares (one 'variant_<name>' share per variant, common/interventions.py:300-323)"""
