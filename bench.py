@@ -56,6 +56,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 HUS_AGENTS = 1685983
 DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg', 'collective')
+# the chip's RANDOM-ACCESS rates, G accesses/s (tools/ubench_random.hip, profiles/r05_evidence/ubench_random.txt: independent of the requests
+# in flight per lane and of the waves per CU -- throughput limits): what bounds k_hosp_install, whose bytes are nothing
+RANDOM_RATES = dict(load=50.0, store=23.0, atomic=18.0, atomic_cached=26.0)
 DAY_IMAGE_BYTES = 101 * 1024   # k_day's LDS image of the contact tables, staged once per workgroup (k_contacts.inc: DayShared + rows)
 
 
@@ -163,6 +166,7 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
         contacts_on_scan_days=float(contacts[1:][(days[:-1] % stride) == 0].mean()
                                     if steps > 1 and ((days[:-1] % stride) == 0).any() else contacts.mean()),
         new_infections_per_day=float(new_inf[1:].mean() if steps > 1 else new_inf.mean()),
+        removed_per_day=float(sc[1:, eng.S_TOTAL_INFECTORS].mean() / world if steps > 1 else sc[:, eng.S_TOTAL_INFECTORS].mean() / world),
         final_all_infected=int(tot('all_infected')[-1]),
         peak_infected=int(tot('infected').max()),
     )
@@ -246,6 +250,15 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
             ent['moved_bytes_per_launch'] = moved_k[k]
             ent['moved_GBs'] = round(moved_k[k] / (us * 1e-6) / 1e9, 2)
             ent['moved'] = round(moved_k[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        if k == 'k_hosp_install':
+            # the kernel's bound is the chip's random-access rate, not bytes: an infection is one load (the target's claim), two atomics
+            # on the bit planes (Infinity-Cache resident), one on the source's count and two stores (the target's word, its infector); an
+            # onset two stores; an agent booked into the R statistics one load -- priced at the measured rates (RANDOM_RATES)
+            r_ = RANDOM_RATES
+            ns = (st['new_infections_per_day'] * (1 / r_['load'] + 2 / r_['atomic_cached'] + 1 / r_['atomic'] + 2 / r_['store'])
+                  + st['new_infections_per_day'] * 2 / r_['store'] + st.get('removed_per_day', 0.0) / r_['load'])
+            ent['random_access'] = {'floor_us': round(ns / 1000.0, 2), 'frac': round(ns / 1000.0 / us, 4),
+                                    'rates_G_per_s': r_, 'note': 'mean day; the launch also pays its 4-5 us dispatch floor and, on ordered days, the bed / ICU walk'}
         if k in util:
             ent['valu'] = {'mean_day': util[k].get('valu_mean_day'), 'peak_day': util[k].get('valu_peak_day')}
             ent['waiting'] = {'mean_day': util[k].get('waiting_mean_day'), 'peak_day': util[k].get('waiting_peak_day')}

@@ -321,7 +321,9 @@ class Context:
             # (the same on every shard -- the segments are exchanged whole --: from the largest shard's size)
             cap = getattr(comm, 'xchg_cap', None)
             largest = int(sum(-(-int(c) // self.n_shards) for c in self.global_age_counts))
-            cfg.xchg_cap = int(cap) if cap else max(2048, largest // (64 * self.n_shards))
+            # (a small population gets relatively more: 16 384 records are 128 KB -- a heavy outbreak among 30 000 agents on two
+            # shards put 2100 records a day into a segment of 2048, found by the randomised soak)
+            cfg.xchg_cap = int(cap) if cap else max(16384, largest // (64 * self.n_shards))
             cfg.pool_cap = max(4096, total // 16)
             # every shard's age_start: a source draws its target on the other shard and needs its age
             tab = np.zeros((self.n_shards, _eng.MAX_AGES + 1), dtype=np.int32)

@@ -23,24 +23,38 @@ if len(sys.argv) > 2 and sys.argv[2] == 'sharded':
         if case % 100 == 99:
             print('sharded soak: %d scenarios so far, %d mismatches, %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
         gm, cm = [], []
+        # (round 5: both attribution modes -- exact: the records through the exchange segments, links checked to be the true ones)
+        attribution = os.environ.get('REINA_SOAK_ATTRIBUTION') or ('exact', 'exact', 'mirror')[case % 3]
         try:
             gpu = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=ivs, ipc=ipc,
-                                           comm=sharding.InProcessComm(r, G, gm)) for r in range(G)]
+                                           comm=sharding.InProcessComm(r, G, gm, attribution=attribution)) for r in range(G)]
             cpu = [simulation.make_context(v, age_counts=ages, seed=seed, interventions=ivs, ipc=ipc,
-                                           comm=sharding.InProcessComm(r, G, cm),
+                                           comm=sharding.InProcessComm(r, G, cm, attribution=attribution),
                                            engine_factory=par_backend.par_engine_factory) for r in range(G)]
             for d in range(min(days, 100)):
                 sharding.step_shards_together(gpu)
                 sharding.step_shards_together(cpu)
                 if d % 10 == 9:
+                    # (a capacity that runs out -- an exchange segment, a list -- fails BOTH runs loudly, but what was dropped
+                    # differs: once both engines have raised the same problem the scenario is over)
+                    pg = int(sharding.reduce_counters(gpu)[T.eng.C_NR * T.eng.MAX_AGES + T.eng.S_PROBLEM])
+                    pc = int(sharding.reduce_counters(cpu)[T.eng.C_NR * T.eng.MAX_AGES + T.eng.S_PROBLEM])
+                    if pg >= 100 or pc >= 100:
+                        assert pg == pc, 'day %d: problem %d on the GPU, %d on the CPU' % (d, pg, pc)
+                        raise StopIteration
                     for a, b in zip(gpu, cpu):
                         assert np.array_equal(a.engine.read_counters(), b.engine.read_counters()), 'day %d' % d
             for a, b in zip(gpu, cpu):
                 assert np.array_equal(a.engine.read_counters(), b.engine.read_counters()), 'final'
                 T._assert_state_equal(a, b)
+            if attribution == 'exact' and not sharding.reduce_counters(gpu)[T.eng.C_NR * T.eng.MAX_AGES + T.eng.S_PROBLEM]:
+                from shard_util import assert_links_are_true
+                assert_links_are_true(gpu)
+        except StopIteration:
+            print('sharded case %d (G=%d, %s): both engines ran out of a capacity (problem %d), skipped' % (case, G, attribution, pg), flush=True)
         except AssertionError as e:
             bad += 1
-            print('MISMATCH sharded case %d (G=%d): %s' % (case, G, str(e)[:300]), flush=True)
+            print('MISMATCH sharded case %d (G=%d, %s): %s' % (case, G, attribution, str(e)[:300]), flush=True)
     print('sharded soak: %d scenarios, %d mismatches, %.0f s' % (n, bad, time.time() - t0))
     sys.exit(0)
 for case in range(n):
