@@ -268,11 +268,11 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
     for k in every_day:
         kernels[k]['share_of_kernel_time'] = round(kernels[k]['avg_launch_us'] / ksum, 4) if ksum else None
     # the engine AS BUILT, restated in bytes: a sparse day streams the ACTIVE bit plane (N / 8), fetches one
-    # 32-byte sector per active agent's word, stages k_day's table image once per workgroup, looks up one sector of the infected
-    # plane per contact that can transmit (1 in 50), and an infection touches five sectors (target word, target record, the
-    # source's count, two plane words), read and written back
+    # 32-byte sector per active agent's word, brings k_day's table image into each of the 8 XCDs' L2 (the workgroups stage it from
+    # there), looks up one sector of the infected plane per contact that can transmit (1 in 50), and an infection touches five
+    # sectors (target word, target record, the source's count, two plane words), read and written back
     sparse = n_agents >= 8_000_000
-    model = ((n_agents / 8.0 if sparse else 4.0 * n_agents) + (32.0 if sparse else 4.0) * st['mean_infected'] + 256 * DAY_IMAGE_BYTES
+    model = ((n_agents / 8.0 if sparse else 4.0 * n_agents) + (32.0 if sparse else 4.0) * st['mean_infected'] + 8 * DAY_IMAGE_BYTES
              + 32.0 * st['contacts_per_day'] / 50.0 + 2 * 5 * 32.0 * st['new_infections_per_day'])
     out = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5),
                traffic=moved_day, scope='whole day: sum of B_alg over the timed days / wall time of the timed region (SURVEY.md 8d)',
@@ -281,7 +281,7 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
                frac_meaning='vs_hot_word_streamer: the day priced at the bytes a kernel that read every agent\'s hot word would move. The engine '
                             'does not (sparse days stream one bit per agent): `moved` is the measured figure',
                moved=None, model_bytes_per_day=round(model, 1),
-               model_formula=('N/8 + 32*N_infected' if sparse else '4*N + 4*N_infected') + ' + 256 workgroups * table image + 32*contacts/50 + 320*new_infections',
+               model_formula=('N/8 + 32*N_infected' if sparse else '4*N + 4*N_infected') + ' + 8 XCDs * table image + 32*contacts/50 + 320*new_infections',
                wasted=None,
                ms_per_step=round(ms_per_step, 6), kernel_us_per_day=round(ksum, 3), kernels=kernels,
                kernel_timing='HIP events (start/stop of the dispatch packet, launch stream) inside the timed region; on a profiled day '

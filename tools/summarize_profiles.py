@@ -51,7 +51,8 @@ per_kernel = {}
 util = {}
 N_SIMD, CLOCK_GHZ = 1024, 2.4   # MI355X: 256 CUs x 4 SIMDs; the shader clock the cycle figures are priced at
 for cfg, key in (('hus', 'hus'), ('husw', 'hus_window'), ('50m', '50000000'), ('100m', '100000000'), ('200m', '200000000')):
-    DAYS = 25 if cfg == 'husw' else 365   # (husw: the driver's window, 5 untimed + 20 timed days -- all of them quiet, all counted)
+    DAYS = 50 if cfg == 'husw' else 365   # (husw: the driver's window, 5 untimed + 20 timed days -- all of them quiet, all counted --, twice:
+    #                                        bench.py runs such a short window a second time for its `cold_count_rows` figure)
     st = newest(os.path.join(G, '%s_trace_%s' % (tag, cfg), '*', '*kernel_stats.csv'))
     if st:
         shutil.copy(st[0], os.path.join(P, '%s_kernel_stats_%s.csv' % (tag, cfg)))
