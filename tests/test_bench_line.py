@@ -1,0 +1,57 @@
+"""The bench line's roofline object (bench.roofline_obj) on recorded numbers, no GPU: what round 4's verdict asked of it -- no
+per-kernel fraction of the HBM peak above 1 under a name that says "fraction", the bytes actually moved beside the algorithmic
+ones, the VALU-issue figures, a bound per regime, and the random-access bound of k_hosp_install."""
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _res(n_agents, day_us, k_day_us, install_us, infected, contacts, new_inf):
+    return dict(dt=day_us * 1e-6 * 365, n_local=n_agents, rccl_world=None,
+                prof={'k_open': (0.0133 * 23, 23), 'k_day': (k_day_us * 1e-3 * 23, 23), 'k_hosp_install': (install_us * 1e-3 * 23, 23)},
+                stats=dict(infected_on_scan_days=infected, mean_infected=infected, contacts_per_day=contacts, contacts_on_scan_days=contacts,
+                           new_infections_per_day=new_inf, removed_per_day=new_inf, final_all_infected=1, peak_infected=1))
+
+
+def test_roofline_object_says_what_bounds_the_engine(monkeypatch):
+    # the 2e8-agent year of round 5's collection: k_day 97.8 us for 841.6 MB of algorithmic bytes = 1.075 x the HBM peak
+    moved = {'k_day': 323_000_000, 'k_hosp_install': 68_000_000}
+    util = {'k_day': dict(valu_mean_day=0.5172, valu_peak_day=0.594, waiting_mean_day=0.52, waiting_peak_day=0.51),
+            'k_hosp_install': dict(valu_mean_day=0.242, valu_peak_day=0.203, waiting_mean_day=0.75, waiting_peak_day=0.77)}
+    monkeypatch.setattr(bench, 'traffic_for', lambda key: (406_277_956, moved, util, 'test'))
+    r = bench.roofline_obj(200_000_000, _res(200_000_000, 168.0, 97.8, 44.1, 3.0e6, 7.8e6, 1.18e5), 365, 16, '200000000')
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4
+    text = json.dumps(r)
+    assert 'frac_of_hbm_peak' not in text                      # (the name that could not be a fraction is gone)
+    kd = r['kernels']['k_day']
+    assert kd['vs_hot_word_streamer'] > 1.0                    # ... the comparison with a streamer may exceed 1, and says what it is
+    assert 0.0 < kd['moved'] < 1.0 and 0.0 < r['moved']['frac'] < 1.0 and r['moved']['frac'] < r['frac']
+    assert r['traffic'] == r['moved']['bytes_per_day'] and r['wasted'] == round(r['moved']['bytes_per_day'] / r['model_bytes_per_day'], 3)
+    assert r['valu']['k_day'] == {'mean_day': 0.5172, 'peak_day': 0.594} and 'k_hosp_install' in r['valu']
+    assert set(r['bound_by_regime']) == {'quiet_day', 'peak_day'} and 'latency' in r['bound_by_regime']['quiet_day'] and 'valu' in r['bound_by_regime']['peak_day']
+    ra = r['kernels']['k_hosp_install']['random_access']
+    assert 0.5 < ra['frac'] <= 1.05 and ra['floor_us'] > 20      # (at 2e8 agents the launch runs close to the chip's random-access rate)
+
+
+def test_no_traffic_means_no_moved_figure():
+    r = bench.roofline_obj(1_685_983, _res(1_685_983, 40.0, 14.0, 12.0, 500.0, 2000.0, 50.0), 365, 16, None)
+    assert r['moved'] is None and r['traffic'] is None and r['wasted'] is None and r['valu'] is None
+    assert 'vs_hot_word_streamer' in r['kernels']['k_day'] and 'moved' not in r['kernels']['k_day']
+
+
+def test_recorded_bench_line_of_the_round_carries_the_new_fields():
+    """profiles/r05_bench.json (the line of the final binary, collected on the GPU box): every full_scenario entry and the headline
+    carry moved / valu / bound_by_regime, no fraction above 1 under the names that are fractions"""
+    b = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench.json')))
+    lines = [b['roofline']] + [fs['roofline'] for fs in b['full_scenario'].values()]
+    assert len(lines) == 5
+    for r in lines:
+        assert r['moved'] and 0 < r['moved']['frac'] < 1 and r['valu'] and r['bound_by_regime'] and 0 < r['frac'] < 1
+        for k, ent in r['kernels'].items():
+            assert 'frac_of_hbm_peak' not in ent
+            if 'moved' in ent:
+                assert 0 < ent['moved'] < 1, (k, ent)
+    assert b['metric'] == 'agent-days/sec' and b['dtype'] == 'u32' and 'cpu_baseline' in b and b['vs_baseline'] is None
