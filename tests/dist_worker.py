@@ -86,6 +86,19 @@ def main():
             assert torch.equal(recv[k * n:(k + 1) * n], want), 'ncclAllToAll through the engine hook: segment %d' % k
         if rank == 0:
             print('direct_alltoall=ok', flush=True)
+    # TorchComm.all_to_all as model.Context._step calls it when the engine does not queue the exchange itself: every rank's
+    # segment k arrives as segment (rank) at rank k -- HBM buffers under nccl, host arrays (uint64) under gloo
+    n = 257
+    if backend == 'nccl':
+        snd = torch.arange(world * n, dtype=torch.int64, device='cuda') + 1000003 * rank
+        rcv = torch.zeros(world * n, dtype=torch.int64, device='cuda')
+    else:
+        snd = (np.arange(world * n, dtype=np.uint64) + np.uint64(1000003 * rank))
+        rcv = np.zeros(world * n, dtype=np.uint64)
+    comm.all_to_all(snd, rcv)
+    got = rcv.cpu().numpy() if backend == 'nccl' else rcv.astype(np.int64)
+    for k in range(world):
+        assert np.array_equal(got[k * n:(k + 1) * n], np.arange(rank * n, (rank + 1) * n) + 1000003 * k), 'TorchComm.all_to_all: segment %d' % k
     ctx = simulation.make_context(v, age_counts=ages, seed=21, engine_factory=factory, device=device, comm=comm)
     if len(sys.argv) > 4 and sys.argv[4] == 'ensemble':
         # config 5 shape: seeds partitioned over the ranks, gathered on rank 0

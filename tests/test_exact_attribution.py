@@ -100,6 +100,35 @@ def test_the_abi_refuses_an_exact_engine_without_its_tables():
         par_backend.par_engine_factory(cfg, dis)
 
 
+def test_an_exact_day_is_stepped_by_phases_not_by_halves():
+    """reina_step_day_begin / _end bracket ONE external collective; a day under exact attribution has up to five exchanges, so the
+    two halves are refused (loudly) and reina_step_phase names the collectives one by one: all-to-alls on a tracing day in the
+    OPEN and TRACE phases, all-reduce + all-to-all after MAIN, an all-to-all after END, nothing after FEEDBACK"""
+    v, ivs = _tracing_scenario()
+    cs = _shards(2, 8000, 3, v=v, ivs=ivs)
+    d, _ = cs[0]._build_day()
+    with pytest.raises(eng.EngineError):
+        cs[0].engine.step_day_begin(d)
+    for day in range(14):   # (contact tracing starts on day 12)
+        days = [c._build_day()[0] for c in cs]
+        want = [eng.X_ALLTOALL if day >= 12 else 0, eng.X_ALLTOALL if day >= 12 else 0, eng.X_ALLREDUCE | eng.X_ALLTOALL, eng.X_ALLTOALL, 0]
+        for ph in range(eng.PH_NR):
+            need = [c.engine.step_phase(dd, ph) for c, dd in zip(cs, days)]
+            assert need == [want[ph]] * 2, (day, ph, need)
+            if need[0] & eng.X_ALLREDUCE:
+                tot = sum(np.asarray(c.engine.tensors['pressure'], dtype=np.int64) for c in cs).astype(np.int32)
+                for c in cs:
+                    c.engine.tensors['pressure'][:] = tot
+            if need[0] & eng.X_ALLTOALL:
+                snd = [np.array(c.engine.tensors['xsend']).reshape(2, -1) for c in cs]
+                for r, c in enumerate(cs):
+                    c.engine.tensors['xrecv'][:] = np.stack([snd[s][r] for s in range(2)]).reshape(-1)
+        for c in cs:
+            c.day += 1
+    assert sharding.reduce_counters(cs)[eng.C_NR * A + eng.S_PROBLEM] == 0
+    assert_links_are_true(cs)
+
+
 @pytest.mark.slow
 def test_a_small_traced_outbreak_decays_like_the_unsharded_one():
     """DESIGN section 6, finding 4 / VERDICT r04 item 1: scenario 87 of tests/diff_a_b.py (31 349 agents, tracing at 92 % from day
