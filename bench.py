@@ -173,7 +173,7 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
     rccl_world = None
     if comm is not None and getattr(comm, 'direct', None) is not None:
         rccl_world = comm.direct.count()
-    return dict(dt=t1 - t0, prof=prof, stats=stats, n_local=ctx.total_people, rccl_world=rccl_world)
+    return dict(dt=t1 - t0, prof=prof, stats=stats, n_local=ctx.total_people, rccl_world=rccl_world, exchange_fill=ctx.exchange_fill())
 
 
 def lib_sha256():
@@ -612,7 +612,8 @@ def main():
             ro = run_gpu(vs_, ages_s, a.seed, 365, 0, device, dist, preheat=0, stride=16, preheat_runs=0, attribution=other)
             ro['dt'] = max_over_ranks(ro['dt'])
             strong_sharded[other] = {'value': round(tot_s * 365 / ro['dt'], 1), 'ms_per_step': round(ro['dt'] * 1000 / 365, 6),
-                                     'kernels': {k: round(ms * 1000 / c, 2) for k, (ms, c) in ro['prof'].items() if c}}
+                                     'kernels': {k: round(ms * 1000 / c, 2) for k, (ms, c) in ro['prof'].items() if c},
+                                     'exchange_segment_fill': dict(zip(('peak_records', 'capacity'), (ro if other == 'exact' else rs)['exchange_fill']))}
         except Exception as e:   # noqa: BLE001 -- reported in the line itself
             strong_sharded[other] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     ens_dist = None

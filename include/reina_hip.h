@@ -144,6 +144,8 @@ enum {
                                                            yet counted into R), word [day & 1]: yesterday's count tells k_day whether to stream
                                                            every hot word or only buffers.active_bits (sparse days) */
     REINA_L_POOL = 26,                                  /* exact attribution: nodes of buffers.infectee_pool handed out so far */
+    REINA_L_XCHG_PEAK = 27,                             /* exact attribution: the most records any exchange segment of this shard has held so far
+                                                           (against reina_config_t.xchg_cap: how close a run came to problem 106) */
     REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
     REINA_L_DET_SIDE = 48,                              /* [REINA_MAX_AGES] the day's detections by age from the test queue (the day's opening
                                                            launch), folded into the counters by the day's last launch */

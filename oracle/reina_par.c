@@ -91,7 +91,11 @@ static void xsend_push(Par *e, uint32_t dest, uint64_t rec) {
     seg[1 + seg[0]++] = rec;
 }
 static void xsend_reset(Par *e) {
-    for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) xseg(e, e->buf.xsend, sh)[0] = 0;
+    for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+        uint64_t *seg = xseg(e, e->buf.xsend, sh);
+        if ((int64_t)seg[0] > CTL(e, REINA_L_XCHG_PEAK)) CTL(e, REINA_L_XCHG_PEAK) = (int32_t)seg[0];
+        seg[0] = 0;
+    }
 }
 /* records shard `sh` sent to this one in the last exchange */
 static uint32_t xrecv_count(const Par *e, uint32_t sh) {

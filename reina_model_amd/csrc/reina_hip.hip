@@ -119,8 +119,9 @@ static bool kind_timed(int today, int kind) {
 // MemberRef by value (k_common.inc: DAY_KERNEL)
 #define LAUNCH_DAY(e, today, kind, kernel, grid, block, lds, stream, ...)                                                \
     do {                                                                                                                 \
-        if (K > 1) LAUNCH_TIMED(e, today, kind, (kernel<true>), grid, block, lds, stream, refs, (e)->h_ref, __VA_ARGS__); \
-        else LAUNCH_TIMED(e, today, kind, (kernel<false>), grid, block, lds, stream, refs, (e)->h_ref, __VA_ARGS__);      \
+        if (K > 1) LAUNCH_TIMED(e, today, kind, (kernel<true, false>), grid, block, lds, stream, refs, (e)->h_ref, __VA_ARGS__);  \
+        else if ((e)->exact) LAUNCH_TIMED(e, today, kind, (kernel<false, true>), grid, block, lds, stream, refs, (e)->h_ref, __VA_ARGS__); \
+        else LAUNCH_TIMED(e, today, kind, (kernel<false, false>), grid, block, lds, stream, refs, (e)->h_ref, __VA_ARGS__); \
     } while (0)
 
 static void resolve_profile(reina_engine *e) {
@@ -399,18 +400,18 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK_OR(hipMalloc(&e->d_ref, sizeof(MemberRef)), free_engine(e));
     HIP_CHECK_OR(hipMemcpy(e->d_params, &e->h_params, sizeof(DevParams), hipMemcpyHostToDevice), free_engine(e));
     HIP_CHECK_OR(hipMemcpy(e->d_tables, &e->h_tables, sizeof(Tables), hipMemcpyHostToDevice), free_engine(e));
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS)), free_engine(e));
-    // (both instantiations of every day kernel that takes dynamic LDS, sized for the larger of its two launch shapes)
+    // (every instantiation of every day kernel that takes dynamic LDS -- single engine, group member, shard under exact attribution --,
+    // sized for the larger of its launch shapes)
     const size_t walk_lds = (size_t)HOSP_P_THREADS * HOSP_P_E * 8, small_lds = (size_t)REINA_MAX_HOSP_EVENTS * 8;
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_presort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds), free_engine(e));
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_presort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds), free_engine(e));
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(walk_lds > small_lds ? walk_lds : small_lds)), free_engine(e));
-    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hosp_install<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(walk_lds > small_lds ? walk_lds : small_lds)), free_engine(e));
+    const int day_lds = (int)day_shared_bytes(REINA_LDS_ROWS, REINA_LDS_CROWS, REINA_MAX_SHARDS), inst_lds = (int)(walk_lds > small_lds ? walk_lds : small_lds);
+#define SET_LDS(kernel, bytes)                                                                                                                       \
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes), free_engine(e)); \
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes), free_engine(e));  \
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes), free_engine(e))
+    SET_LDS(k_day, day_lds);
+    SET_LDS(k_hosp_presort, (int)walk_lds);
+    SET_LDS(k_hosp_install, inst_lds);
+#undef SET_LDS
     *out = e;
     return REINA_OK;
 }

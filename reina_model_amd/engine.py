@@ -44,6 +44,7 @@ S_NR = 32
 COUNTER_WORDS = C_NR * MAX_AGES + S_NR
 L_NR = 48 + MAX_AGES   # REINA_L_NR (48 named words and cursors + the detections-by-age side block)
 L_POOL = 26        # control word (exact attribution): nodes of infectee_pool handed out
+L_XCHG_PEAK = 27   # control word (exact attribution): the fullest any exchange segment has been (against Config.xchg_cap)
 L_HOSP_PEAK = 12   # control word: bed / ICU event count of the busiest day on which the events' order mattered
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
 ABI_VERSION = 5   # reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays; round 4: the two per-agent bit planes; round 5: exact cross-shard attribution -- exchange buffers, infectee pool, reina_step_phase)

@@ -735,6 +735,14 @@ class Context:
     def synchronize(self):
         self._raise_on_problem(self._read_counters_global())
 
+    def exchange_fill(self):
+        """exact attribution: (the most records any exchange segment of THIS shard has held so far, the segments' capacity) -- how
+        close the run came to problem 106; (0, 0) for a population that exchanges no records"""
+        if self.attribution != 'exact':
+            return 0, 0
+        ctl = self.engine.alloc.to_host(self.engine.tensors['control'])
+        return int(ctl[_eng.L_XCHG_PEAK]), int(self.engine.config.xchg_cap)
+
     def _raise_on_problem(self, counters):
         problem = int(counters[_eng.C_NR * _eng.MAX_AGES + _eng.S_PROBLEM])
         if problem != 0:

@@ -64,6 +64,8 @@ def test_every_link_is_the_true_one(G):
     assert info['links'] > 3000 and info['cross_shard'] > info['links'] * (G - 1) // (2 * G)
     assert info['listed'] > 1000
     assert sum(int(np.asarray(c.engine.tensors['control'])[eng.L_POOL]) for c in cs) > 0, 'no list spilled into the pool'
+    peak, cap = cs[0].exchange_fill()   # (how close the run came to a full exchange segment: problem 106)
+    assert cap == 16384 and 50 < peak < cap, (peak, cap)
     assert pop('all_detected') > 500
 
 

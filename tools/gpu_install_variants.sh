@@ -3,10 +3,10 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; TAG=${1:-iv}; mkdir -p $OUT; cd $R
 F="--offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fast-math"
 /opt/rocm/bin/hipcc $F -DREINA_NO_BYBIT -o /tmp/lib_nobybit.so reina_model_amd/csrc/reina_hip.hip 2>/dev/null &
-/opt/rocm/bin/hipcc $F -DREINA_NO_BYBIT -DREINA_NO_EXACT -o /tmp/lib_noexact.so reina_model_amd/csrc/reina_hip.hip 2>/dev/null &
+
 wait
 for n in 1685983; do
-for v in final nobybit noexact; do
+for v in final nobybit; do
   if [ $v = final ]; then L=""; else L=/tmp/lib_$v.so; fi
   REINA_HIP_LIB=$L python tools/day_modes.py $n 365 auto 2>/dev/null | grep "^# mean" | sed "s/^/$n $v /"
   python - <<PY
@@ -16,4 +16,4 @@ v=np.array([r.get('k_hosp_install',0) for r in d]); o=np.array([r.get('k_open',0
 PY
 done; done | tee $OUT/${TAG}_variants.txt
 cd /tmp && rm -rf old && tar xf $R/old_tree_r04.tar && cd /tmp/old && python -c "from reina_model_amd import build; build.build(verbose=False)" > /dev/null 2>&1
-for k in 1 2; do (cd /tmp/old && python tools/day_modes.py 1685983 365 auto 2>/dev/null | grep '^# mean' | sed 's/^/old /'); (cd $R && python tools/day_modes.py 1685983 365 auto 2>/dev/null | grep '^# mean' | sed 's/^/new /'); (cd $R && REINA_HIP_LIB=/tmp/lib_noexact.so python tools/day_modes.py 1685983 365 auto 2>/dev/null | grep '^# mean' | sed 's/^/noexact /'); done | tee -a $OUT/${TAG}_variants.txt
+for k in 1 2; do (cd /tmp/old && python tools/day_modes.py 1685983 365 auto 2>/dev/null | grep '^# mean' | sed 's/^/old /'); (cd $R && python tools/day_modes.py 1685983 365 auto 2>/dev/null | grep '^# mean' | sed 's/^/new /'); done | tee -a $OUT/${TAG}_variants.txt
