@@ -213,7 +213,9 @@ def traffic_for(key):
             str(tj.get('lib_sha256'))[:12], tj.get('commit'))
     val = tj.get('per_day_bytes', {}).get(key)
     strip = lambda d: {k.split('<')[0]: v for k, v in d.items()}
-    return (val, strip(tj.get('per_kernel_bytes_per_day', {}).get(key, {})), strip(tj.get('utilisation', {}).get(key, {})),
+    # (the SQ passes are collected over the 365-day scenarios: a short window of the same population carries the year's figures)
+    util = tj.get('utilisation', {}).get(key) or (tj.get('utilisation', {}).get('hus', {}) if key == 'hus_window' else {})
+    return (val, strip(tj.get('per_kernel_bytes_per_day', {}).get(key, {})), strip(util),
             'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the kernels of a day, mean over the scenario; collected on %s; commit %s' % (how, tj.get('commit')))
 
 
