@@ -67,9 +67,39 @@ def main():
     attribution = os.environ.get('REINA_TEST_ATTRIBUTION', 'exact')   # cross-shard infector links (sharding.py)
     comm = sharding.TorchComm(attribution=attribution)
     comm.always_collective = True  # exercise the phases and their collectives even when world == 1
+    if len(sys.argv) > 4 and sys.argv[4] == 'instream' and backend == 'gloo':
+        # the engine's OWN day loop (step_day: the phases in C, the collectives called through the function pointers of
+        # reina_set_collective / reina_set_alltoall) across real processes: the pointers are ctypes callbacks that run the gloo
+        # collectives on the host buffers -- what DirectRccl's ncclAllReduce / ncclAllToAll are to the HIP engine
+        import ctypes
+
+        def _allreduce(send, recv, count, dtype, op, comm_, stream):
+            assert dtype == 2 and op == 0 and send == recv
+            buf = np.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_int32)), shape=(count,))
+            t = torch.from_numpy(buf)
+            dist.all_reduce(t)
+            return 0
+
+        def _alltoall(send, recv, count, dtype, comm_, stream):
+            assert dtype == 4
+            s_ = torch.from_numpy(np.ctypeslib.as_array(ctypes.cast(send, ctypes.POINTER(ctypes.c_int64)), shape=(count * world,)))
+            r_ = torch.from_numpy(np.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_int64)), shape=(count * world,)))
+            dist.all_to_all_single(r_, s_)
+            return 0
+
+        class FakeDirect:   # (the attributes model.Context reads of sharding.DirectRccl)
+            pass
+        fd = FakeDirect()
+        fd._keep = (ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)(_allreduce),
+                    ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)(_alltoall))
+        fd.fn_ptr = ctypes.cast(fd._keep[0], ctypes.c_void_p).value
+        fd.a2a_ptr = ctypes.cast(fd._keep[1], ctypes.c_void_p).value
+        fd.comm_ptr = 1
+        fd.count = lambda: world
+        comm.direct = fd
     if rank == 0:
         print('direct_rccl=%s' % (comm.direct is not None), flush=True)
-    if comm.direct is not None:
+    if comm.direct is not None and backend == 'nccl':
         # the exchange of exact attribution as the engine queues it: RCCL's ncclAllToAll through the function pointer
         # reina_set_alltoall receives (count per peer, ncclInt64 = 4), on the day stream, with this rank's own communicator --
         # every rank's segment k must arrive as segment (rank) at rank k
@@ -115,6 +145,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if len(sys.argv) > 4 and sys.argv[4] == 'instream':
+        assert ctx._in_stream, 'the run must go through the engine\'s own day loop'
     hist = ctx.run(days)
     final = ctx.generate_state()
     if rank == 0:

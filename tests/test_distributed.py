@@ -39,6 +39,17 @@ def test_gloo_sharded_run_equals_in_process_sharded_run(world, attribution):
     assert 'attribution=%s' % (attribution if world > 1 else 'none') in r.stdout
 
 
+@pytest.mark.parametrize('attribution', ['exact', 'mirror'])
+def test_the_engines_own_day_loop_with_the_collectives_behind_function_pointers(attribution):
+    """reina_step_day / reina_run_days run the phases of a day in C and call the collectives through the pointers of
+    reina_set_collective / reina_set_alltoall (RCCL's ncclAllReduce / ncclAllToAll on the day stream in production).  Here, with the
+    CPU checker's same loop (par_step_day) and ctypes callbacks that run the gloo collectives: world 2, 130 days incl. two weeks of
+    contact tracing == the same sharded run stepped phase by phase in one process."""
+    r = _launch(2, 'gloo', 130, 30000, mode='instream', timeout=600, extra_env={'REINA_TEST_ATTRIBUTION': attribution})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'DIST_OK world=2' in r.stdout and 'attribution=%s' % attribution in r.stdout
+
+
 def test_gloo_ensemble_is_partitioned_over_the_ranks():
     """BASELINE config 5 (replicas only): 7 seeds over 2 ranks, gathered on rank 0, every member identical
     to its single run"""
