@@ -141,8 +141,8 @@ enum {
     REINA_L_IMPORT_SYNC,                                /* [4] arrival words of the workgroups that share a day's weekly imports (zeroed by the
                                                            day's last launch) */
     REINA_L_ACTIVE = 24,                                /* [2] agents the daily stream found something to do for (infected, or removed and not
-                                                           yet counted into R), word [day & 1]: yesterday's count tells k_day whether to stream
-                                                           every hot word or only buffers.active_bits (sparse days) */
+                                                           yet counted into R), word [day & 1] (a diagnostic: rounds 4-5 chose the form of
+                                                           k_day's stream by yesterday's count; the launch now does, by population size) */
     REINA_L_POOL = 26,                                  /* exact attribution: nodes of buffers.infectee_pool handed out so far */
     REINA_L_XCHG_PEAK = 27,                             /* exact attribution: the most records any exchange segment of this shard has held so far
                                                            (against reina_config_t.xchg_cap: how close a run came to problem 106) */

@@ -291,17 +291,13 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
             const int v = std::atoi(w);
             if (v >= 1 && v <= 16) e->import_wgs = (uint32_t)v;
         }
-        // k_day streams the bit plane instead of the hot words when yesterday's stream found fewer than n_agents / div active
-        // agents (k_contacts.inc).  REINA_DAY_MODE = dense | sparse forces one form (the tests run every scenario in both),
-        // REINA_DAY_SPARSE_DIV moves the threshold, REINA_DAY_FLAGS are k_day's measurement switches (DAY_F_*)
-        e->day_sparse_below = REINA_DAY_SPARSE_DIV_DEFAULT <= 1u ? 0xFFFFFFFFu : cfg->n_agents / REINA_DAY_SPARSE_DIV_DEFAULT;
-        if (const char *w = std::getenv("REINA_DAY_SPARSE_DIV")) {
-            const int v = std::atoi(w);
-            if (v >= 1) e->day_sparse_below = cfg->n_agents / (uint32_t)v;
-        }
+        // k_day streams the ACTIVE bit plane instead of the hot words when the population is large enough for that form to pay
+        // (day_is_sparse).  REINA_DAY_MODE = dense | sparse forces one form whatever the size (the tests run every scenario in
+        // both), alternate switches between them day by day; REINA_DAY_FLAGS are k_day's measurement switches
         if (const char *w = std::getenv("REINA_DAY_MODE")) {
-            if (!std::strcmp(w, "dense")) e->day_sparse_below = 0u;
-            else if (!std::strcmp(w, "sparse")) { e->day_sparse_below = 0xFFFFFFFFu; e->day_flags |= DAY_F_SPARSE_ANY; }
+            if (!std::strcmp(w, "dense")) e->day_mode = 1;
+            else if (!std::strcmp(w, "sparse")) e->day_mode = 2;
+            else if (!std::strcmp(w, "alternate")) e->day_mode = 3;
         }
         if (const char *w = std::getenv("REINA_DAY_FLAGS")) e->day_flags |= (uint32_t)std::atoi(w);
         if (const char *w = std::getenv("REINA_OPEN_TICKETS")) e->open_tickets = std::atoi(w) != 0;   // (the tests' handle on the ticket path of a single engine)
@@ -408,7 +404,13 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes), free_engine(e)); \
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes), free_engine(e));  \
     HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes), free_engine(e))
-    SET_LDS(k_day, day_lds);
+#define SET_LDS_DAY(SP)                                                                                                                              \
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<false, false, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, day_lds), free_engine(e)); \
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<true, false, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, day_lds), free_engine(e));  \
+    HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_day<false, true, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, day_lds), free_engine(e))
+    SET_LDS_DAY(false);
+    SET_LDS_DAY(true);
+#undef SET_LDS_DAY
     SET_LDS(k_hosp_presort, (int)walk_lds);
     SET_LDS(k_hosp_install, inst_lds);
 #undef SET_LDS
@@ -797,8 +799,21 @@ static int launch_day_main(reina_engine_t *e, const MemberRef *refs, uint32_t K,
         if (++e->vacc_seq == 0u) e->vacc_seq = 1u;
         LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(vg, K), dim3(PRO_THREADS), 0, s, dp, e->vacc_seq, geo);
     }
-    LAUNCH_DAY(e, today, REINA_PK_DAY, k_day, dim3(day_blocks + stream_imports, K), dim3(DAY_THREADS), day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards), s, dp, lds_rows, lds_crows,
-               e->day_sparse_below, e->day_flags, stream_imports);
+    {
+        // the form of the stream (k_contacts.inc): sparse from DAY_SPARSE_MIN_TILES tiles per wave on -- every day of such a population:
+        // a threshold on yesterday's active agents (rounds 4-5, decided in the kernel) never chose the dense form where the sparse
+        // one was possible
+        const uint32_t tiles = ((e->cfg.n_agents >> 2) + 127u) / 128u;
+        bool sparse = e->day_mode == 2 || (e->day_mode == 0 && tiles >= DAY_SPARSE_MIN_TILES * day_blocks * DAY_WAVES);
+        if (e->day_mode == 3) sparse = (dp.day & 1u) == 0u;
+        const dim3 grid(day_blocks + stream_imports, K), block(DAY_THREADS);
+        const size_t lds = day_shared_bytes(lds_rows, lds_crows, e->cfg.n_shards);
+#define K_DAY(G, X, SP) LAUNCH_TIMED(e, today, REINA_PK_DAY, (k_day<G, X, SP>), grid, block, lds, s, refs, (e)->h_ref, dp, lds_rows, lds_crows, e->day_flags, stream_imports)
+        if (K > 1) { if (sparse) K_DAY(true, false, true); else K_DAY(true, false, false); }
+        else if (e->exact) { if (sparse) K_DAY(false, true, true); else K_DAY(false, true, false); }
+        else { if (sparse) K_DAY(false, false, true); else K_DAY(false, false, false); }
+#undef K_DAY
+    }
     e->cur_scan_waves = day_blocks * DAY_WAVES;   // (the day's later launches walk the per-wave slices)
     if (e->cfg.n_shards > 1) {
         // a sharded population: its event buckets sorted and their maps written to the exchange block BEFORE the all-reduce

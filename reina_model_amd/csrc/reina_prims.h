@@ -97,9 +97,13 @@ RP_HD uint32_t rp_contact_ctr(uint32_t day, uint32_t c, uint32_t half) { return 
 // reina_contacts.h: rc_count_thresholds): its own key, counter (agent, day)
 // (never 0xFFFFFFFF: that value is the thresholds' "never" -- a count row of an age without contacts is all 0xFFFFFFFF, and
 // the searches test r >= threshold -- so the one draw in 2^32 that would pass it is folded onto its neighbour)
-RP_HD uint32_t rp_count_draw(uint32_t k0, uint32_t k1, uint32_t who, uint32_t day) {
-    const uint32_t r = rp_philox2(rp_contact_key(k0, k1) ^ 0x6A09E667u, who, day).v[0];
+// (keyed: with rp_contact_key(k0, k1) already at hand)
+RP_HD uint32_t rp_count_draw_keyed(uint32_t contact_key, uint32_t who, uint32_t day) {
+    const uint32_t r = rp_philox2(contact_key ^ 0x6A09E667u, who, day).v[0];
     return r == 0xFFFFFFFFu ? 0xFFFFFFFEu : r;
+}
+RP_HD uint32_t rp_count_draw(uint32_t k0, uint32_t k1, uint32_t who, uint32_t day) {
+    return rp_count_draw_keyed(rp_contact_key(k0, k1), who, day);
 }
 
 // Purposes (counter word c2 low byte). The sub-index (contact number, import try, tracer id)

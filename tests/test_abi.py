@@ -98,7 +98,8 @@ def test_kernels_fit_the_lds_they_ask_for():
             fields, name = {}, None
     day = [v for k, v in kernels.items() if 'k_day' in k]
     hosp = [v for k, v in kernels.items() if 'k_hosp_install' in k]
-    assert len(day) == 3 and len(hosp) == 3, sorted(kernels)   # (three instantiations each: single engine / engine group / shard under exact attribution)
+    # (single engine / engine group / shard under exact attribution; k_day in its two forms, dense and sparse stream)
+    assert len(day) == 6 and len(hosp) == 3, sorted(kernels)
     LDS = 160 * 1024
     # dynamic requests: reina_hip.hip (day_shared_bytes(REINA_LDS_ROWS, sharded), REINA_MAX_HOSP_EVENTS * 8)
     for h in hosp:

@@ -1,8 +1,9 @@
 """Per-day kernel times of one scenario with k_day forced dense, forced sparse, and choosing by itself (round 4).
-usage: python tools/day_modes.py [agents] [days] [modes...]    (modes: dense sparse auto tickets imports_open; default: dense sparse auto)
+usage: python tools/day_modes.py [agents] [days] [modes...]    (modes: dense sparse auto alternate tickets imports_open; default: dense sparse auto)
 Each day is stepped alone and every kernel of it timed (HIP events, profile stride 1), so the times carry the event
 overhead of a fully timed day (a few us) -- the comparison between modes is what this is for: from which share of active
-agents on does streaming the hot words beat fetching the active ones (REINA_DAY_SPARSE_DIV_DEFAULT)?"""
+agents on does streaming the hot words beat fetching the active ones?  (Measured, rounds 4-5: never where the sparse form
+is possible -- the launch picks the form by population size alone.)"""
 import copy
 import json
 import os
@@ -25,7 +26,7 @@ def run(agents, days, mode):
         os.environ['REINA_OPEN_TICKETS'] = '1'
     if mode == 'imports_open':
         os.environ['REINA_IMPORTS_IN_OPEN'] = '1' 
-    if mode in ('dense', 'sparse'):
+    if mode in ('dense', 'sparse', 'alternate'):
         os.environ['REINA_DAY_MODE'] = mode
     v, ages = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), agents)
     ctx = simulation.make_context(v, age_counts=ages, seed=0)
@@ -67,4 +68,5 @@ if __name__ == '__main__':
                 if k not in ('day', 'infected'):
                     tot[k] = tot.get(k, 0.0) + x
         print('# mean us/day %-9s %s  sum %.1f' % (m, ' '.join('%s %.1f' % (k, x / days) for k, x in sorted(tot.items())), sum(tot.values()) / days))
+        print('# max  us     %-9s %s' % (m, ' '.join('%s %.1f' % (k, max(r.get(k, 0.0) for r in out[m])) for k in sorted(tot))))
     json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'day_modes_%d.json' % agents), 'w'))

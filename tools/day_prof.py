@@ -37,5 +37,12 @@ for day in days:
         last = wg.max(axis=1) / 1000.0
         print('   workgroups %d: loop of the LAST wave of a workgroup min %.1f mean %.1f max %.1f kcycles; of the FIRST wave mean %.1f' % (
             len(wg), last.min(), last.mean(), last.max(), (wg.min(axis=1) / 1000.0).mean()))
+    if len(wg):   # the pieces of this part by a wave's rank in its workgroup's finishing order (the pool hands batches to the early ones)
+        pieces = allr[:nwg * 16, 2].reshape(nwg, 16)[allr[:nwg * 16, 0].reshape(nwg, 16).max(axis=1) > 0]
+        order = np.argsort(wg, axis=1)
+        byrank = np.take_along_axis(pieces, order, axis=1).mean(axis=0)
+        loops = np.take_along_axis(wg, order, axis=1).mean(axis=0) / 1000.0
+        print('   pieces by finishing rank: ' + ' '.join('%.1f' % x for x in byrank))
+        print('   loop kcycles by rank:     ' + ' '.join('%.0f' % x for x in loops))
     print('part %s day %d: k_day %.1f us; per wave: whole loop %.1f kcycles (slowest %.1f), this part %.1f kcycles in %.1f pieces (%.2f kcycles each)' % (
         what, day, k['k_day'][0] * 1000.0, rows[:, 0].sum() / waves / 1000.0, (rows[:, 0].max() if len(rows) else 0.0) / 1000.0, rows[:, 1].sum() / waves / 1000.0, rows[:, 2].sum() / waves, rows[:, 1].sum() / max(1.0, rows[:, 2].sum()) / 1000.0))
