@@ -91,11 +91,18 @@ def _shared_comm(sharding, attribution='mirror'):
     return _COMM[attribution]
 
 
+TIMED_LAUNCH_COST_US = 8.0   # wall time a timestamped dispatch adds to a short run (tools/window_probe.py: 20 HUS days with 15 / 3 / 0 of them)
+
+
 def stride_for(steps, time_every):
-    """profiled days: one kind of kernel per profiled day; short runs profile every day (stride 4)"""
+    """profiled days: one kind of kernel per profiled day, the four kinds at phases 0, 1/4, 1/2, 3/4 of the stride -- any `stride`
+    consecutive days time every kernel once.  A timestamped dispatch adds about 8 us of wall time to a short run
+    (TIMED_LAUNCH_COST_US): until round 5 a run of fewer than 64 days timed one kernel EVERY day, and the round driver's 20-day
+    window carried 15 of them -- 6 us a step of a 39 us step, the instrument a seventh of the measurement.  Now: stride 8 below
+    64 days (the window: two or three samples of each kernel, 7 dispatches), 16 from there on, 4 for runs shorter than 16 days."""
     if time_every:
         return max(4, int(time_every) // 4 * 4)
-    return 4 if steps < 64 else 8 if steps < 160 else 16
+    return 4 if steps < 16 else 8 if steps < 64 else 16
 
 
 def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=16, preheat_runs=2, attribution='mirror'):
@@ -287,7 +294,9 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
                wasted=None,
                ms_per_step=round(ms_per_step, 6), kernel_us_per_day=round(ksum, 3), kernels=kernels,
                kernel_timing='HIP events (start/stop of the dispatch packet, launch stream) inside the timed region; on a profiled day '
-                             'one kind of kernel is timed: stride %d days per kind' % stride)
+                             'one kind of kernel is timed: stride %d days per kind (%d timestamped dispatches in the timed region, about '
+                             '%.0f us of wall time each: tools/window_probe.py)' % (
+                                 stride, sum(int(x.get('timed_launches', 0)) for x in kernels.values()), TIMED_LAUNCH_COST_US))
     if moved_day:
         # `moved`: HBM bytes per day from the PMC counters / the day's wall time / peak -- north_star's "achieved HBM GB/s against the
         # chip's peak" read literally; `wasted`: moved bytes over the restated model's (sector granularity included)

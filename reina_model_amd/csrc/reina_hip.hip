@@ -300,6 +300,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
             else if (!std::strcmp(w, "alternate")) e->day_mode = 3;
         }
         if (const char *w = std::getenv("REINA_DAY_FLAGS")) e->day_flags |= (uint32_t)std::atoi(w);
+        if (const char *w = std::getenv("REINA_EXPORT")) e->export_by_copies = !std::strcmp(w, "memcpy");
         if (const char *w = std::getenv("REINA_OPEN_TICKETS")) e->open_tickets = std::atoi(w) != 0;   // (the tests' handle on the ticket path of a single engine)
         if (const char *w = std::getenv("REINA_IMPORTS_IN_OPEN")) e->imports_in_open = std::atoi(w) != 0;   // (the round-3 placement, for comparison)
     }
@@ -1133,8 +1134,29 @@ int reina_read_history(reina_engine_t *e, const int32_t *history_dev, uint32_t n
     if (!e->bound) return REINA_E_NOT_BOUND;
     hipStream_t s = (hipStream_t)stream;
     const size_t row = sizeof(int32_t) * REINA_COUNTER_WORDS;
-    if (n_rows) HIP_CHECK(hipMemcpyAsync(out_host, history_dev, row * n_rows, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(out_host + (size_t)n_rows * REINA_COUNTER_WORDS, e->buf.counters, row, hipMemcpyDeviceToHost, s));
+    static_assert(sizeof(int32_t) * REINA_COUNTER_WORDS % 16 == 0, "rows are copied 16 bytes at a time");
+    // a page-locked destination (what engine.py passes) is written by a kernel, over the link: one launch instead of the copy
+    // engine's two set-ups (REINA_EXPORT=memcpy: the copies, for comparison)
+    void *export_dev = nullptr;
+    {
+        hipPointerAttribute_t at;
+        std::memset(&at, 0, sizeof(at));
+        if (!e->export_by_copies && hipPointerGetAttributes(&at, out_host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer &&
+            (reinterpret_cast<uintptr_t>(at.devicePointer) & 15u) == 0u)
+            export_dev = at.devicePointer;
+        else
+            (void)hipGetLastError();   // (pageable memory is not an error here: it takes the copies below)
+    }
+    if (export_dev && (n_rows == 0 || (reinterpret_cast<uintptr_t>(history_dev) & 15u) == 0u)) {
+        const uint32_t n_hist4 = (uint32_t)(row * n_rows / 16), n_cnt4 = (uint32_t)(row / 16);
+        const uint32_t blocks = (n_hist4 + n_cnt4 + 255u) / 256u;
+        hipLaunchKernelGGL(k_export, dim3(blocks < 64u ? blocks : 64u), dim3(256), 0, s, reinterpret_cast<const uint4 *>(history_dev), n_hist4,
+                           reinterpret_cast<const uint4 *>(e->buf.counters), n_cnt4, reinterpret_cast<uint4 *>(export_dev));
+        HIP_CHECK(hipGetLastError());
+    } else {
+        if (n_rows) HIP_CHECK(hipMemcpyAsync(out_host, history_dev, row * n_rows, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(out_host + (size_t)n_rows * REINA_COUNTER_WORDS, e->buf.counters, row, hipMemcpyDeviceToHost, s));
+    }
     HIP_CHECK(hipStreamSynchronize(s));
     return REINA_OK;
 }
