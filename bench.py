@@ -203,6 +203,9 @@ def src_sha256():
     return h.hexdigest()
 
 
+_TRACE_US = {}
+
+
 def traffic_for(key):
     """PMC figures of profiles/traffic.json for configuration `key`, only if collected on this very binary (or on a build of
     the very sources): (bytes per day, {kernel: bytes per day}, {kernel: utilisation figures}, note)"""
@@ -222,6 +225,8 @@ def traffic_for(key):
     strip = lambda d: {k.split('<')[0]: v for k, v in d.items()}
     # (the SQ passes are collected over the 365-day scenarios: a short window of the same population carries the year's figures)
     util = tj.get('utilisation', {}).get(key) or (tj.get('utilisation', {}).get('hus', {}) if key == 'hus_window' else {})
+    global _TRACE_US
+    _TRACE_US = tj.get('kernel_trace_us', {}).get(key, {})   # rocprofv3 --kernel-trace of the same 365-day command (roofline_obj)
     return (val, strip(tj.get('per_kernel_bytes_per_day', {}).get(key, {})), strip(util),
             'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the kernels of a day, mean over the scenario; collected on %s; commit %s' % (how, tj.get('commit')))
 
@@ -240,8 +245,10 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
         'k_hosp_install': 12.0 * st['new_infections_per_day'],
     }
     moved_day, moved_k, util, note = (None, {}, {}, None)
+    trace = {}
     if traffic_key is not None:
         moved_day, moved_k, util, note = traffic_for(traffic_key)
+        trace = dict(_TRACE_US) if moved_day else {}
     kernels, ksum = {}, 0.0
     for k in DAY_KERNELS:
         ms, n = prof.get(k, (0.0, 0))
@@ -268,6 +275,11 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
                   + st['new_infections_per_day'] * 2 / r_['store'] + st.get('removed_per_day', 0.0) / r_['load'])
             ent['random_access'] = {'floor_us': round(ns / 1000.0, 2), 'frac': round(ns / 1000.0 / us, 4),
                                     'rates_G_per_s': r_, 'note': 'mean day; the launch also pays its 4-5 us dispatch floor and, on ordered days, the bed / ICU walk'}
+        if k in trace:
+            # the same kernel in rocprofv3's kernel trace of the same command (profiles/): mean over ALL its launches of the year, every
+            # dispatch timestamped alike -- a timestamped dispatch among plain ones (the HIP-event figure above) measures about 1 us more
+            ent['trace_avg_launch_us'] = trace[k][1]
+            ent['trace_launches'] = trace[k][2]
         if k in util:
             ent['valu'] = {'mean_day': util[k].get('valu_mean_day'), 'peak_day': util[k].get('valu_peak_day')}
             ent['waiting'] = {'mean_day': util[k].get('waiting_mean_day'), 'peak_day': util[k].get('waiting_peak_day')}
@@ -297,6 +309,11 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
                              'one kind of kernel is timed: stride %d days per kind (%d timestamped dispatches in the timed region, about '
                              '%.0f us of wall time each: tools/window_probe.py)' % (
                                  stride, sum(int(x.get('timed_launches', 0)) for x in kernels.values()), TIMED_LAUNCH_COST_US))
+    if trace:
+        # the kernels' time per simulated day by rocprofv3's trace of the same 365-day command (kernels that do not run every day
+        # count with the days they run): what the step is to be compared with -- the sum of the HIP-event means above carries the
+        # price of a timestamped dispatch among plain ones and can exceed the mean step
+        out['kernel_us_per_day_trace'] = round(sum(v[0] for v in trace.values()), 3)
     if moved_day:
         # `moved`: HBM bytes per day from the PMC counters / the day's wall time / peak -- north_star's "achieved HBM GB/s against the
         # chip's peak" read literally; `wasted`: moved bytes over the restated model's (sector granularity included)

@@ -49,6 +49,7 @@ def day_kernel(n):
 per_day = {}
 per_kernel = {}
 util = {}
+trace_us = {}   # key -> kernel -> [us per simulated day, mean us per launch, launches]: rocprofv3 --kernel-trace of the same command
 N_SIMD, CLOCK_GHZ = 1024, 2.4   # MI355X: 256 CUs x 4 SIMDs; the shader clock the cycle figures are priced at
 for cfg, key in (('hus', 'hus'), ('husw', 'hus_window'), ('50m', '50000000'), ('100m', '100000000'), ('200m', '200000000')):
     DAYS = 50 if cfg == 'husw' else 365   # (husw: the driver's window, 5 untimed + 20 timed days -- all of them quiet, all counted --, twice:
@@ -75,6 +76,8 @@ for cfg, key in (('hus', 'hus'), ('husw', 'hus_window'), ('50m', '50000000'), ('
                             round(float(np.percentile(d, 90)), 2), round(d.max(), 2)] +
                            [round(d[int(len(d) * p / 100)], 1) for p in range(0, 100, 10)])
             w.writerow(['SUM of kernel time per simulated day', '', round(tot, 2)])
+            trace_us[key] = {n.split('<')[0]: [round(float(np.array([x[1] for x in ks[n]]).sum()) / DAYS, 3),
+                                               round(float(np.array([x[1] for x in ks[n]]).mean()), 3), len(ks[n])] for n in sorted(ks)}
     rows = [['kernel', 'counter', 'launches', 'mean_KB_per_launch', 'max_KB', 'KB_per_simulated_day', 'HBM_bytes_per_day (FETCH x2)']]
     tot, ok, pk = 0.0, True, {}
     for kind, cname, mult in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE', 1.0)):
@@ -152,7 +155,9 @@ if per_day and os.path.exists(sha_f):
     sys.path.insert(0, ROOT)
     import bench as _bench
     json.dump({'lib_sha256': open(sha_f).read().strip(), 'src_sha256': _bench.src_sha256(), 'commit': commit, 'tag': tag, 'per_day_bytes': per_day,
-               'per_kernel_bytes_per_day': per_kernel, 'utilisation': util,
+               'per_kernel_bytes_per_day': per_kernel, 'utilisation': util, 'kernel_trace_us': trace_us,
+               '_kernel_trace_us': 'per kernel [us per simulated day, mean us per launch, launches] from rocprofv3 --kernel-trace of the same 365-day '
+                                   'command (every dispatch timestamped alike)',
                '_utilisation': 'per kernel, from the SQ passes of the same binary: valu = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch cycles at '
                                '2.4 GHz), waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES; mean day = sums over the 365 launches, peak day = the longest launch',
                '_comment': 'HBM bytes per simulated day summed over every kernel of the day: rocprofv3 --pmc FETCH_SIZE and '
