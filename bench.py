@@ -91,12 +91,13 @@ def _shared_comm(sharding, attribution='mirror'):
     return _COMM[attribution]
 
 
-TIMED_LAUNCH_COST_US = 8.0   # wall time a timestamped dispatch adds to a short run (tools/window_probe.py: 20 HUS days with 15 / 3 / 0 of them)
+TIMED_LAUNCH_COST_US = 5.5   # wall time a timestamped dispatch adds to a short run (tools/window_probe.py: 20 HUS days with 15 / 3 / 0 of them;
+#                              8 us with events of the default, system-scope release: the engine's timing events release to the device)
 
 
 def stride_for(steps, time_every):
     """profiled days: one kind of kernel per profiled day, the four kinds at phases 0, 1/4, 1/2, 3/4 of the stride -- any `stride`
-    consecutive days time every kernel once.  A timestamped dispatch adds about 8 us of wall time to a short run
+    consecutive days time every kernel once.  A timestamped dispatch adds 5.5-8 us of wall time to a short run
     (TIMED_LAUNCH_COST_US): until round 5 a run of fewer than 64 days timed one kernel EVERY day, and the round driver's 20-day
     window carried 15 of them -- 6 us a step of a 39 us step, the instrument a seventh of the measurement.  Now: stride 8 below
     64 days (the window: two or three samples of each kernel, 7 dispatches), 16 from there on, 4 for runs shorter than 16 days."""

@@ -71,11 +71,14 @@ static int grid_for(uint32_t n_items, int threads, int max_blocks) {
 // HIP-event timing of the day's kernels (reina_profile_enable): start/stop timestamps ride on the kernel's
 // own dispatch packet (hipExtLaunchKernelGGL), no extra stream commands.  On a profiled day ONE kind of kernel
 // is timed (the kinds take turns), so the cost of timestamped dispatches is spread thinly over the run.
+// (the events only carry timestamps, read after a synchronisation: a DEVICE-scope release where they are recorded -- the default, a
+// system-scope release, writes the caches back behind every timestamped kernel)
+#define REINA_TIMING_EVENT_FLAGS (hipEventReleaseToDevice)
 static bool take_event_pair(reina_engine *e, size_t *a, size_t *b) {
     while (e->ev_used + 2 > e->ev_pool.size()) {
         if (e->ev_pool.size() >= reina_engine::MAX_EVENTS) return false;   // pool exhausted: this launch goes untimed
         hipEvent_t ev = nullptr;
-        if (hipEventCreate(&ev) != hipSuccess || !ev) return false;
+        if (hipEventCreateWithFlags(&ev, REINA_TIMING_EVENT_FLAGS) != hipSuccess || !ev) return false;
         e->ev_pool.push_back(ev);
     }
     *a = e->ev_used++;
@@ -1168,7 +1171,7 @@ int reina_profile_enable(reina_engine_t *e, int enable) {
     // create timing events up front: hipEventCreate inside a timed region costs microseconds each
     while (e->profile && e->ev_pool.size() < 1024) {
         hipEvent_t ev;
-        HIP_CHECK(hipEventCreate(&ev));
+        HIP_CHECK(hipEventCreateWithFlags(&ev, REINA_TIMING_EVENT_FLAGS));
         e->ev_pool.push_back(ev);
     }
     return REINA_OK;
