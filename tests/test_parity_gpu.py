@@ -1098,6 +1098,36 @@ def test_config5_per_gpu_batch_of_128_hus_members():
     assert hist[:, -1, i * A:(i + 1) * A].sum(axis=1).min() > 100_000
 
 
+def test_the_history_comes_back_the_same_by_kernel_and_by_copies(monkeypatch):
+    """reina_read_history (round 5): a page-locked destination is written by one small kernel over the link, anything else -- and every
+    destination under REINA_EXPORT=memcpy -- by two copies.  Same rows, same final counter block, through all three: the kernel
+    (engine.py's page-locked block), the copies forced, and a pageable numpy array handed to the library directly."""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=12, icu_units=2)
+    ages = datasets.scaled_population(30000)
+    days = 37   # (an odd number of rows: the copy goes 16 bytes at a time)
+
+    def one(force_copies):
+        if force_copies:
+            monkeypatch.setenv('REINA_EXPORT', 'memcpy')
+        else:
+            monkeypatch.delenv('REINA_EXPORT', raising=False)
+        ctx = simulation.make_context(v, age_counts=ages, seed=5)
+        hist = ctx.run(days, record_history=True)
+        return ctx, np.array(hist)
+
+    ctx_k, by_kernel = one(False)
+    ctx_c, by_copies = one(True)
+    assert by_kernel.shape == (days, eng.COUNTER_WORDS) and np.array_equal(by_kernel, by_copies)
+    assert by_kernel.any() and not np.array_equal(by_kernel[0], by_kernel[-1])   # (rows of a running epidemic, not a block of zeros)
+    # a pageable destination: the library's own fallback, on the engine that writes by kernel otherwise
+    e = ctx_k.engine
+    dev = e.alloc.empty(4 * eng.COUNTER_WORDS, np.int32)
+    out = np.zeros(2 * eng.COUNTER_WORDS, dtype=np.int32)
+    e._check(e.f['read_history'](e._h, e.alloc.ptr(dev), 0, out.ctypes.data, e.alloc.stream()), 'read_history')
+    assert np.array_equal(out[:eng.COUNTER_WORDS], e.read_counters())
+
+
 def test_driver_contract_on_the_hip_engine():
     """SURVEY 8 f-3 through libreina_hip.so: simulate_individuals' (df, adf) (calc/simulation.py:148-290), the
     step_callback protocol incl. interruption, sample_model_parameters (:293-347) and run_monte_carlo
