@@ -55,3 +55,23 @@ def test_recorded_bench_line_of_the_round_carries_the_new_fields():
             if 'moved' in ent:
                 assert 0 < ent['moved'] < 1, (k, ent)
     assert b['metric'] == 'agent-days/sec' and b['dtype'] == 'u32' and 'cpu_baseline' in b and b['vs_baseline'] is None
+
+
+def test_the_instrument_is_thin_in_a_short_window():
+    """A timestamped dispatch costs wall time (5.5-8 us: tools/window_probe.py), and the round driver's window is 20 days long: a run of
+    16-63 days times one kernel every other day (stride 8: each of the four phases twice or three times in 20 days), a longer one every
+    fourth day, only the shortest every day -- and any `stride` consecutive days still time every kind once."""
+    assert bench.stride_for(20, 0) == 8 and bench.stride_for(64, 0) == 16 and bench.stride_for(365, 0) == 16 and bench.stride_for(5, 0) == 4
+    assert bench.stride_for(20, 12) == 12 and bench.stride_for(365, 2) == 4   # (--time-every: multiples of four, at least four)
+    for steps, warmup in ((20, 5), (30, 0), (365, 5)):
+        stride = bench.stride_for(steps, 0)
+        phases = {0: 0, stride // 4: 0, stride // 2: 0, stride // 2 + stride // 4: 0}   # (reina_hip.hip: profiled_kind)
+        for day in range(warmup, warmup + steps):
+            if day % stride in phases:
+                phases[day % stride] += 1
+        assert min(phases.values()) >= 1, (steps, phases)
+        if steps == 20:
+            assert sum(phases.values()) <= 10 and min(phases.values()) >= 2   # (15 of them until round 5's last day)
+    # the trace's per-kernel means ride on the line beside the HIP-event means when profiles/traffic.json matches the binary
+    r = bench.roofline_obj(1_685_983, _res(1_685_983, 40.0, 14.0, 12.0, 500.0, 2000.0, 50.0), 365, 16, None)
+    assert 'kernel_us_per_day_trace' not in r and 'timestamped dispatches' in r['kernel_timing']
