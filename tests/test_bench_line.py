@@ -75,3 +75,43 @@ def test_the_instrument_is_thin_in_a_short_window():
     # the trace's per-kernel means ride on the line beside the HIP-event means when profiles/traffic.json matches the binary
     r = bench.roofline_obj(1_685_983, _res(1_685_983, 40.0, 14.0, 12.0, 500.0, 2000.0, 50.0), 365, 16, None)
     assert 'kernel_us_per_day_trace' not in r and 'timestamped dispatches' in r['kernel_timing']
+
+
+def test_line_fits():
+    """Round 5's line was 24.5 KB and the round driver could not parse it (BENCH_r05.json: parsed null).  The printed line is a
+    digest of at most 8000 bytes -- contract fields, roofline (headline + per-size table), cpu_baseline, ensemble --, the full
+    objects go to profiles/bench_detail.json."""
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_driver_window.json')))   # the 24.5 KB object of round 5
+    line = bench.compact_line(full)
+    text = json.dumps(line, separators=(',', ':'))
+    assert len(text) < bench.LINE_LIMIT <= 8000 and '\n' not in text
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in line, k
+    r = line['roofline']
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(r) and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4
+    assert set(r['full_scenario_365d']) == {'hus', '50000000', '100000000', '200000000'}
+    big = r['full_scenario_365d']['100000000']
+    assert big['k_day']['trace_us'] and big['k_day']['pmc_bytes'] and 0 < big['moved_frac'] < big['frac'] < 1
+    c = line['cpu_baseline']
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(c) and c['kind'] == 'port' and c['all_cores']['cores'] >= 1
+    assert line['ensemble']['value'] > 0 and 'model' not in line['config']
+    # a line that still does not fit sheds its widest optional parts instead of growing
+    fat = json.loads(json.dumps(full))
+    for k in list(fat['full_scenario']):
+        for j in range(40):
+            fat['full_scenario']['%s_%d' % (k, j)] = fat['full_scenario'][k]
+    thin = bench.compact_line(fat)
+    assert len(json.dumps(thin, separators=(',', ':'))) < bench.LINE_LIMIT and thin.get('truncated') and 'cpu_baseline' in thin
+
+
+def test_recorded_line_of_this_round_parses_and_fits():
+    """profiles/r06_bench_line.json holds the line exactly as bench.py printed it on the GPU box (when it has been collected)"""
+    p = os.path.join(ROOT, 'profiles', 'r06_bench_line.json')
+    if not os.path.exists(p):
+        import pytest
+        pytest.skip('no recorded line yet')
+    text = open(p).read().strip()
+    assert len(text) < 8000 and len(text.splitlines()) == 1
+    line = json.loads(text)
+    assert line['roofline']['frac'] > 0 and line['cpu_baseline']['value'] > 0 and line['dtype'] == 'u32'
