@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -800,7 +801,12 @@ static int launch_day_main(reina_engine_t *e, const MemberRef *refs, uint32_t K,
             }
             if (vg < 1u) vg = 1u;
         }
-        if (++e->vacc_seq == 0u) e->vacc_seq = 1u;
+        // The tag is drawn from ONE process-wide counter (round-5 advisor): the tagged words live in each member's own buffers and
+        // are never cleared, so a per-engine counter could come back to a value those buffers already hold -- a member stepped in
+        // a group (tag = the representative's count) and later alone or under another representative.  A process-wide value is
+        // never reused on any buffers (2^32 - 1 vaccination launches per process before it wraps).
+        static std::atomic<uint32_t> vacc_seq_next{0};
+        do e->vacc_seq = ++vacc_seq_next; while (e->vacc_seq == 0u);
         LAUNCH_DAY(e, today, REINA_PK_VACCINATE, k_vaccinate, dim3(vg, K), dim3(PRO_THREADS), 0, s, dp, e->vacc_seq, geo);
     }
     {
@@ -1150,7 +1156,10 @@ int reina_read_history(reina_engine_t *e, const int32_t *history_dev, uint32_t n
         else
             (void)hipGetLastError();   // (pageable memory is not an error here: it takes the copies below)
     }
-    if (export_dev && (n_rows == 0 || (reinterpret_cast<uintptr_t>(history_dev) & 15u) == 0u)) {
+    // (k_export reads 16 bytes a lane: the history rows AND the counter block -- a C-ABI caller may have bound either at any
+    // 4-byte offset into a block of its own; anything not 16-byte aligned takes the copies below)
+    if (export_dev && (n_rows == 0 || (reinterpret_cast<uintptr_t>(history_dev) & 15u) == 0u) &&
+        (reinterpret_cast<uintptr_t>(e->buf.counters) & 15u) == 0u) {
         const uint32_t n_hist4 = (uint32_t)(row * n_rows / 16), n_cnt4 = (uint32_t)(row / 16);
         const uint32_t blocks = (n_hist4 + n_cnt4 + 255u) / 256u;
         hipLaunchKernelGGL(k_export, dim3(blocks < 64u ? blocks : 64u), dim3(256), 0, s, reinterpret_cast<const uint4 *>(history_dev), n_hist4,

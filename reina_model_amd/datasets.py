@@ -14,23 +14,27 @@ from dataclasses import dataclass
 
 import numpy as np
 
-_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'fi_hus.json')
+_DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+_DATA = os.path.join(_DATA_DIR, 'fi_hus.json')
+# area name (variables['area_name']) -> bundled file: the age histogram the reference computes from data/005_11re_2019.csv
+# (a municipality, or the municipalities of a hospital district: calc/datasets.py:48-61) and the rows of the area's case file
+# (AREA_CASEFILES, calc/datasets.py:82-86), recorded by tests/golden/make_golden.py / make_turku.py
+_AREAS = {'HUS': 'fi_hus.json', 'Turku': 'fi_turku.json'}
 _cache = {}
 
 
-def _load():
-    if 'd' not in _cache:
-        with open(_DATA) as f:
-            _cache['d'] = json.load(f)
-    return _cache['d']
+def _load(area_name='HUS'):
+    if area_name not in _AREAS:
+        raise KeyError('no bundled data for area %r (have %s)' % (area_name, ', '.join(sorted(_AREAS))))
+    if area_name not in _cache:
+        with open(os.path.join(_DATA_DIR, _AREAS[area_name])) as f:
+            _cache[area_name] = json.load(f)
+    return _cache[area_name]
 
 
 def get_population_for_area(area_name='HUS'):
-    """Age histogram int64[A] (index = age). Only the bundled area is available offline."""
-    d = _load()
-    if area_name != d['area_name']:
-        raise KeyError('no bundled population for area %r (have %r)' % (area_name, d['area_name']))
-    return np.asarray(d['age_counts'], dtype=np.int64)
+    """Age histogram int64[A] (index = age) of a bundled area (calc/datasets.py:48-61)."""
+    return np.asarray(_load(area_name)['age_counts'], dtype=np.int64)
 
 
 def scaled_population(total, base=None):
@@ -47,7 +51,7 @@ def get_contacts_per_day(country='FI'):
 
     Returns a list of tuples (place_type: str, participant_age: int, (cmin, cmax), contacts: float).
     """
-    d = _load()
+    d = _load('HUS')            # (the FI rows of data/contact_matrix.csv travel with the HUS file)
     if country != d['country']:
         raise KeyError('no bundled contact matrix for country %r' % country)
     if 'rows' in _cache:
@@ -102,9 +106,7 @@ def get_initial_population_condition(variables):
     """calc/datasets.py:143-177: measured numbers (dead, in ICU, in ward, confirmed) from the
     area's case file row of the start date, unmeasured ones from the variables; a start date the
     file does not list means an empty initial condition (as the reference, which prints a note)."""
-    d = _load()
-    if variables['area_name'] != d['area_name']:
-        raise KeyError('no bundled case file for area %r' % variables['area_name'])
+    d = _load(variables['area_name'])
     for row in d['case_rows']:
         if row[0] == variables['start_date']:
             return InitialPopulationCondition(

@@ -246,6 +246,11 @@ class Context:
         self.attribution = getattr(comm, 'attribution', 'exact') if self.n_shards > 1 else 'none'
         if self.attribution not in ('exact', 'mirror', 'none'):
             raise ValueError("comm.attribution must be 'exact' or 'mirror'")
+        if self.attribution == 'exact' and not (hasattr(comm, 'all_to_all') or getattr(self._direct, 'a2a_ptr', None)):
+            # (a comm object written for the one all-reduce of rounds 1-4 has no `attribution` and would be switched to exact
+            # attribution silently, to fail with AttributeError on the first stepped day: round-5 advisor)
+            raise TypeError("exact attribution (sharding.DEFAULT_ATTRIBUTION; SURVEY 8 f-4) exchanges records: the comm object "
+                            "must provide all_to_all(send, recv), or set comm.attribution = 'mirror' for one all-reduce a day")
         population_params = dict(population_params)
         ipc = population_params.pop('initial_population_condition', None)
 
@@ -588,6 +593,8 @@ class Context:
             # pressure block with the bed / ICU event maps), and under exact attribution the record exchanges
             for ph in range(_eng.PH_NR):
                 need = self.engine.step_phase(d, ph)
+                if ph == _eng.PH_MAIN and self.always_collective:
+                    need |= _eng.X_ALLREDUCE   # (a single shard asks for no exchange: the world-1 tests exercise the call anyway)
                 if need & _eng.X_ALLREDUCE:
                     self.comm.all_reduce_sum(self.engine.tensors['pressure'])
                 if need & _eng.X_ALLTOALL:

@@ -1,14 +1,27 @@
-"""Model variables: names, units and default values of the reference's `variables.py:227-435`.
+"""Model variables: names, units and default values of the reference's `variables.py:227-435`, its override sets
+(`VARIABLE_OVERRIDE_SETS`, variables.py:10-216) and the module-level accessors a driver script uses (variables.py:451-536).
 
 The engine keeps the reference's variable NAMES and UNITS (every `p_*` / `ratio_*` is a
 percentage, converted by `simulation.create_disease_params` exactly like
 calc/simulation.py:50-61) so existing scenario definitions run unchanged.  Default VALUES are the
 reference's HUS defaults (recorded from the reference by tests/golden/make_golden.py into
-tests/golden/inputs.json; this literal is generated from that record).  The Flask-session
-override plumbing of the reference (variables.py:451-536) is out of scope: `copy_variables` hands out a
-dict, a scenario is that dict with some values changed.
+tests/golden/inputs.json; this literal is generated from that record).
+
+Override sets (round 6): `VARIABLE_OVERRIDE_SETS['turku']` -- Turku's beds / ICU units, its intervention history to 2021-06 (nine
+contact-tracing steps, place-specific mask ladders, weekly imports with a growing variant share) and its scenarios with
+`add_interventions` (`astra-zeneca`: ['vaccinate', '2021-03-15', 2000, 25, 55]) -- is data recorded from the module the reference
+imports (tests/golden/make_turku.py -> data/override_sets.json).  As in the reference, the environment variable
+VARIABLE_OVERRIDE_SET selects a set for the process (variables.py:218-220, :436-437: VARIABLE_DEFAULTS.update(set)); a caller
+can also ask for one explicitly: `copy_variables(override_set='turku')`.
+
+The Flask-session store behind the reference's accessors is web plumbing (out of scope); `get_variable` /
+`set_variable` / `reset_variable(s)` / `allow_set_variable` keep their names and their behaviour OUTSIDE a request context: a
+process-wide override table that `set_variable` may only write inside `allow_set_variable()`.
 """
 import copy
+import json
+import os
+from contextlib import contextmanager
 
 VARIABLE_DEFAULTS = {'area_name': 'HUS',
  'country': 'FI',
@@ -140,13 +153,83 @@ VARIABLE_DEFAULTS = {'area_name': 'HUS',
 
 
 
-def copy_variables(**overrides):
-    """A fresh, caller-owned copy of the defaults (what a driver passes as `variables`), with `overrides` applied: every key must
-    be a known variable.  (The reference keeps a Flask-session override store behind its variables -- variables.py:451-536 --, web
-    plumbing SURVEY section 2 #5 marks out of scope: here a scenario is a dict.)"""
+def _load_override_sets():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'override_sets.json')
+    with open(path, encoding='utf-8') as f:
+        return json.load(f)
+
+
+VARIABLE_OVERRIDE_SETS = _load_override_sets()
+HUS_DEFAULTS = copy.deepcopy(VARIABLE_DEFAULTS)    # the defaults with no override set applied, whatever the environment says
+
+_variable_override_set = os.getenv('VARIABLE_OVERRIDE_SET')
+if _variable_override_set:
+    assert _variable_override_set in VARIABLE_OVERRIDE_SETS
+    VARIABLE_DEFAULTS.update(copy.deepcopy(VARIABLE_OVERRIDE_SETS[_variable_override_set]))   # variables.py:436-437
+
+# variables.py:440-441, :449: overrides set later programmatically
+_variable_overrides = {}
+_allow_variable_set = False
+
+
+def set_variable(var_name, value):
+    """variables.py:452-467 outside a request context: only inside `allow_set_variable()`"""
+    assert var_name in VARIABLE_DEFAULTS
+    assert isinstance(value, type(VARIABLE_DEFAULTS[var_name]))
+    if not _allow_variable_set:
+        raise Exception('Should not set variable outside of request context')
+    _variable_overrides[var_name] = value
+
+
+def get_variable(var_name, var_store=None):
+    """variables.py:470-491: the store given, else the process-wide override, else the default; lists are handed out as copies"""
+    out = None
+    if var_store is not None:
+        out = var_store.get(var_name)
+    elif var_name in _variable_overrides:
+        out = _variable_overrides[var_name]
+    if out is None:
+        out = VARIABLE_DEFAULTS[var_name]
+    if isinstance(out, list):
+        return list(out)
+    return out
+
+
+def reset_variable(var_name):
+    _variable_overrides.pop(var_name, None)
+
+
+def reset_variables():
+    _variable_overrides.clear()
+
+
+@contextmanager
+def allow_set_variable():
+    """variables.py:525-536"""
+    global _allow_variable_set
+    old = _allow_variable_set
+    _allow_variable_set = True
+    try:
+        yield None
+    finally:
+        _allow_variable_set = old
+
+
+def copy_variables(override_set=None, **overrides):
+    """A fresh, caller-owned copy of the variables (what a driver passes as `variables`; variables.py:518-522: every name through
+    `get_variable`, so process-wide overrides show), then -- extensions of this package -- the named override set on top of the
+    plain defaults (`override_set='turku'`, or `'hus'` / `'none'` for the defaults whatever VARIABLE_OVERRIDE_SET says) and
+    `overrides`, every key of which must be a known variable."""
     unknown = sorted(set(overrides) - set(VARIABLE_DEFAULTS))
     if unknown:
         raise KeyError('unknown variable(s): %s' % ', '.join(unknown))
-    out = copy.deepcopy(VARIABLE_DEFAULTS)
+    if override_set is None:
+        out = {name: copy.deepcopy(get_variable(name)) for name in VARIABLE_DEFAULTS}
+    else:
+        out = copy.deepcopy(HUS_DEFAULTS)
+        if str(override_set).lower() not in ('hus', 'none', ''):
+            if override_set not in VARIABLE_OVERRIDE_SETS:
+                raise KeyError('unknown override set %r (have %s)' % (override_set, ', '.join(sorted(VARIABLE_OVERRIDE_SETS))))
+            out.update(copy.deepcopy(VARIABLE_OVERRIDE_SETS[override_set]))
     out.update(copy.deepcopy(overrides))
     return out

@@ -15,9 +15,12 @@ def load_run(name):
 
 
 def variables_for(meta):
-    from reina_model_amd.variables import VARIABLE_DEFAULTS
-    v = copy.deepcopy(VARIABLE_DEFAULTS)
-    v.update(meta['variables'])
+    from reina_model_amd.variables import copy_variables
+    # (runs recorded under an override set of the reference -- VARIABLE_OVERRIDE_SET=turku, tests/golden/make_turku.py -- say so)
+    v = copy_variables(override_set=meta.get('override_set') or 'hus')
+    v.update(copy.deepcopy(meta['variables']))
+    if meta.get('scenario'):
+        v['active_scenario'] = meta['scenario']
     return v
 
 

@@ -1,6 +1,7 @@
 """Host-side logic of the product: contact-table builder, intervention conversion, day descriptors,
 parameter expansion.  CPU only; the engine is replaced by oracle B where one is needed."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -405,3 +406,78 @@ def test_frames_equal_the_reference_drivers_own_frames():
             assert ours[:cut] == line[:cut] and float(line[cut:]) >= 0, (d, ours, line)
         else:
             assert ours == line, (d, ours, line)
+
+
+def test_turku_override_set_equals_the_references():
+    """variables.py:10-216 as the reference's module holds it (tests/golden/turku_inputs.json, recorded by make_turku.py with
+    VARIABLE_OVERRIDE_SET=turku): every variable of the merged defaults, the scenario ids and their add_interventions"""
+    import json
+    import os
+    from reina_model_amd import datasets, variables as V
+    t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'turku_inputs.json')))
+    v = V.copy_variables(override_set='turku')
+    for k, x in t['variable_defaults'].items():
+        assert v[k] == x, k
+    assert [s['id'] for s in v['scenarios']] == t['scenario_ids']
+    assert {s['id']: s.get('add_interventions', []) for s in v['scenarios']} == t['add_interventions']
+    assert ['vaccinate', '2021-03-15', 2000, 25, 55] in t['add_interventions']['astra-zeneca']
+    assert v['area_name'] == 'Turku' and v['hospital_beds'] == 900 and v['icu_units'] == 55
+    assert sum(1 for iv in v['interventions'] if iv[0] == 'test-with-contact-tracing') == 9
+    assert list(datasets.get_population_for_area('Turku')) == t['age_counts'] and sum(t['age_counts']) == 192962
+    # the defaults themselves are untouched, an unknown set is refused, and 'hus' means "no set"
+    assert V.copy_variables()['area_name'] == 'HUS' and V.copy_variables(override_set='hus') == V.copy_variables()
+    with pytest.raises(KeyError):
+        V.copy_variables(override_set='tampere')
+    with pytest.raises(KeyError):
+        datasets.get_population_for_area('Tampere')
+    # Turku's case file feeds the initial condition (calc/datasets.py:138-173): a listed start date, and one it does not list
+    v.update(start_date='2020-09-01', incubating_at_simulation_start=150, ill_at_simulation_start=50, recovered_at_simulation_start=1000)
+    ipc = datasets.get_initial_population_condition(v)
+    assert (ipc.dead, ipc.in_icu, ipc.in_ward, ipc.confirmed_cases, ipc.incubating, ipc.ill, ipc.recovered) == (7, 0, 0, 479, 150, 50, 1000)
+    v['start_date'] = '2020-02-18'
+    assert not datasets.get_initial_population_condition(v).has_initial_state()
+
+
+def test_override_set_is_selected_by_the_environment_like_the_reference():
+    """variables.py:218-220, :436-437: VARIABLE_OVERRIDE_SET picks the process's defaults at import time"""
+    import subprocess
+    import sys
+    code = ('import reina_model_amd.variables as V; v = V.copy_variables(); '
+            'print(v["area_name"], v["hospital_beds"], len(v["scenarios"]), V.copy_variables(override_set="hus")["area_name"])')
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VARIABLE_OVERRIDE_SET='turku'), capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['Turku', '900', '3', 'HUS']
+    bad = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VARIABLE_OVERRIDE_SET='nowhere'), capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert bad.returncode != 0 and 'AssertionError' in bad.stderr
+
+
+def test_reference_shaped_variable_accessors():
+    """variables.py:452-536 outside a request context: get_variable (store, override, default; lists copied), set_variable only
+    inside allow_set_variable(), reset_variable(s), and copy_variables() seeing the overrides (round-5 advisor: scripts written
+    against the reference's module)"""
+    from reina_model_amd import variables as V
+    assert V.get_variable('hospital_beds') == 2600
+    assert V.get_variable('hospital_beds', var_store={'hospital_beds': 12}) == 12
+    ivs = V.get_variable('interventions')
+    ivs.append('x')
+    assert 'x' not in V.get_variable('interventions')
+    with pytest.raises(Exception, match='outside of request context'):
+        V.set_variable('hospital_beds', 10)
+    with V.allow_set_variable():
+        V.set_variable('hospital_beds', 10)
+        with pytest.raises(AssertionError):
+            V.set_variable('hospital_beds', 'ten')
+        with pytest.raises(AssertionError):
+            V.set_variable('no_such_variable', 1)
+    try:
+        assert V.get_variable('hospital_beds') == 10 and V.copy_variables()['hospital_beds'] == 10
+        assert V.copy_variables(override_set='hus')['hospital_beds'] == 2600
+        V.reset_variable('hospital_beds')
+        assert V.get_variable('hospital_beds') == 2600
+        with V.allow_set_variable():
+            V.set_variable('icu_units', 1)
+    finally:
+        V.reset_variables()
+    assert V.get_variable('icu_units') == 300

@@ -175,3 +175,32 @@ def test_cli_day_table_matches_the_recorded_run(capsys):
     cli.main(['--days', '25', '--seed', '1', '--check'])
     out = capsys.readouterr().out
     assert 'all 25 days identical' in out and out.count('\n') >= 27
+
+
+TURKU_RUNS = (['turku_default_s%d' % s for s in range(3)] + ['turku_astra-zeneca_s%d' % s for s in range(3)] +
+              ['turku_stop-wearing-masks_s%d' % s for s in range(2)] + ['turku_autumn_s%d' % s for s in range(2)])
+
+
+@pytest.mark.parametrize('name', TURKU_RUNS)
+def test_turku_override_set_bit_exact(name):
+    """The reference's other deployment (variables.py:10-216, VARIABLE_OVERRIDE_SET=turku; recorded by tests/golden/make_turku.py
+    through the reference's own get_population_for_area / get_initial_population_condition / get_active_interventions): Turku's
+    192 962 agents over 470 days -- nine contact-tracing steps, place-specific mask ladders, weekly imports with a growing
+    variant share, and in the `astra-zeneca` scenario the `vaccinate` programme from 2021-03-15; `autumn`: the start date the set
+    keeps commented out (2020-09-01), whose initial condition comes from the rows of Turku's case file."""
+    z, meta = load_run(name)
+    # the interventions the package derives from its own variables are the ones the reference applied
+    from reina_model_amd import interventions as ivs
+    from reina_model_amd import datasets
+    v = variables_for(meta)
+    mine = [iv.make_iv_tuple() for iv in ivs.get_active_interventions(v)]
+    assert mine == meta['interventions']
+    assert list(datasets.get_population_for_area(v['area_name'])) == meta['age_counts']
+    ipc = datasets.get_initial_population_condition(v)
+    if meta['ipc'] is None:
+        assert not ipc.has_initial_state()
+    else:
+        assert {k: int(getattr(ipc, k)) for k in meta['ipc']} == meta['ipc']
+    if 'astra' in name or 'autumn' in name:
+        assert z['pop'][-1, POP13.index('vaccinated')].sum() > 10000
+    _run_and_compare(name)
