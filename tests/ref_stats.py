@@ -47,11 +47,8 @@ def load_ref(family):
 
 
 def variables_for(meta):
-    import copy
-    from reina_model_amd.variables import VARIABLE_DEFAULTS
-    v = copy.deepcopy(VARIABLE_DEFAULTS)
-    v.update(meta['variables'])
-    return v
+    import golden_util
+    return golden_util.variables_for(meta)    # (the override set and the scenario a family was recorded under included)
 
 
 def series_from_history(hist, meta, ctx):

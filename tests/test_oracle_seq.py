@@ -203,4 +203,4 @@ def test_turku_override_set_bit_exact(name):
         assert {k: int(getattr(ipc, k)) for k in meta['ipc']} == meta['ipc']
     if 'astra' in name or 'autumn' in name:
         assert z['pop'][-1, POP13.index('vaccinated')].sum() > 10000
-    _run_and_compare(name)
+    _run_and_compare(name, max_days=200 if name.endswith('_s2') else None)   # (the third seeds: through the first autumn)

@@ -132,6 +132,20 @@ def test_mini_kitchen_sink(name):
                      interventions=meta['interventions'])
 
 
+@pytest.mark.parametrize('name', ['turku_default_s0', 'turku_astra-zeneca_s1', 'turku_stop-wearing-masks_s0', 'turku_autumn_s0'])
+def test_turku_override_set(name):
+    """the reference's other deployment (variables.py:10-216, VARIABLE_OVERRIDE_SET=turku): 192 962 agents x 470 days -- nine
+    contact-tracing steps, place-specific mask ladders, weekly imports with a variant share growing to 99 %, the `vaccinate`
+    programme of the astra-zeneca scenario; `autumn`: the 2020-09-01 start with the initial condition from Turku's case rows"""
+    _, meta = load_run(name)
+    v = variables_for(meta)
+    assert v['area_name'] == 'Turku' and v['hospital_beds'] == 900
+    gpu, _ = _run_and_compare(v, np.asarray(meta['age_counts']), meta['seed'], meta['days'], interventions=meta['interventions'],
+                              ipc=meta.get('ipc'), chunk=235)
+    if 'astra' in name or 'autumn' in name:
+        assert gpu.generate_state()['vaccinated'].sum() > 10000
+
+
 def test_mini_imports_only():
     _, meta = load_run('mini_imports_s1')
     _run_and_compare(variables_for(meta), np.asarray(meta['age_counts']), meta['seed'], meta['days'],

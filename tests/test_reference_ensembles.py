@@ -9,6 +9,10 @@ and scalar at 4.5 sigma with no relative slack, variance ratios, KS on per-run o
                365 days); plus the NEGATIVE CONTROL: the same comparison with infectiousness_multiplier
                biased by 3 % must fail.
   -m "not gpu" oracle B (bit-identical to the HIP engine, tests/test_parity_gpu.py) on the mini families.
+
+Round 6: the family `turku_astra-zeneca` -- the reference's other deployment (VARIABLE_OVERRIDE_SET=turku, variables.py:10-216):
+192 962 agents x 470 days, scenario `astra-zeneca` (the `vaccinate` programme from 2021-03-15), 64 runs of the real reference
+(tests/golden/make_turku.py).
 """
 import pytest
 
@@ -19,7 +23,7 @@ N_CPU = 128
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('family', ['hus_default', 'mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial'])
+@pytest.mark.parametrize('family', ['hus_default', 'mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial', 'turku_astra-zeneca'])
 def test_hip_engine_samples_the_reference_distribution(family):
     par, meta = ref_stats.run_parallel_ensemble(family, range(70000, 70000 + N_GPU))
     ref, _ = ref_stats.load_ref(family)
@@ -65,7 +69,7 @@ def test_eight_shards_against_the_reference_distribution():
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize('family', ['mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial'])
+@pytest.mark.parametrize('family', ['mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial', 'turku_astra-zeneca'])
 def test_oracle_b_samples_the_reference_distribution(family):
     import par_backend
     par, meta = ref_stats.run_parallel_ensemble(family, range(60000, 60000 + N_CPU), engine_factory=par_backend.par_engine_factory)
@@ -77,10 +81,10 @@ def test_reference_ensembles_are_what_the_generator_describes():
     """fixture sanity (no engine): shapes, seeds disjoint from the single-run goldens, conservation in
     every recorded reference run"""
     import numpy as np
-    for family in ('hus_default', 'mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial'):
+    for family in ('hus_default', 'mini_default', 'mini_imports', 'mini_kitchen', 'mini_initial', 'turku_astra-zeneca'):
         z, meta = ref_stats.load_ref(family)
         S, D, _ = z['tot'].shape
-        assert S >= 128 and D == meta['days'] and len(set(z['seeds'].tolist())) == S and z['seeds'].min() >= 1000
+        assert S >= (64 if family.startswith('turku') else 128) and D == meta['days'] and len(set(z['seeds'].tolist())) == S and z['seeds'].min() >= 1000
         idx = {n: i for i, n in enumerate(meta['pop13'])}
         n = sum(meta['age_counts'])
         t = z['tot'].astype(np.int64)
