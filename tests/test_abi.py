@@ -111,10 +111,9 @@ def test_kernels_fit_the_lds_they_ask_for():
     # k_day addresses v104..v127 by hand (three tiles in flight, inline asm): the kernel descriptor must allocate them
     assert all(d['.vgpr_count:'] == 128 for d in day), day
     for k, v in kernels.items():
-        # the streaming kernel must not touch scratch; the day's last launch (event walk + installs in one kernel) may
-        # park a handful of registers in its engine-group instantiation, none in the single-engine one
-        limit = 32 if 'k_hosp_installILb1' in k else 0
-        assert v.get('.vgpr_spill_count:', 0) <= limit, (k, v)
+        # no kernel touches scratch (round 6: the engine-group instantiation of the day's last launch parked 8 registers in 28
+        # bytes of it until its member reference came through the constant address space: k_common.inc MEMBER_OF_LAUNCH)
+        assert v.get('.vgpr_spill_count:', 0) == 0 and v.get('.private_segment_fixed_size:', 0) == 0, (k, v)
 
 
 def test_k_day_keeps_its_hand_reserved_registers_to_itself():
