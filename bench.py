@@ -289,13 +289,16 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
     ksum = sum(kernels[k]['avg_launch_us'] for k in every_day)
     for k in every_day:
         kernels[k]['share_of_kernel_time'] = round(kernels[k]['avg_launch_us'] / ksum, 4) if ksum else None
-    # the engine AS BUILT, restated in bytes: a sparse day streams the ACTIVE bit plane (N / 8), fetches one
-    # 32-byte sector per active agent's word, brings k_day's table image into each of the 8 XCDs' L2 (the workgroups stage it from
-    # there), looks up one sector of the infected plane per contact that can transmit (1 in 50), and an infection touches five
-    # sectors (target word, target record, the source's count, two plane words), read and written back
+    # the engine AS BUILT, restated in bytes at the memory side's CALIBRATED granularity (round 6: tools/ubench_pmc.hip,
+    # profiles/pmc_calibration.json -- every read request that leaves L2 is a 128-byte line, whatever the load's width, two loads
+    # of one line 64 bytes apart are one request; scattered stores and atomics are 32-byte sectors): a sparse day streams the
+    # ACTIVE bit plane (N / 8) and fetches one LINE per active agent's word, brings k_day's table image into each of the 8
+    # XCDs' L2, looks up one line of the infected plane per contact that can transmit (1 in 50), and an infection reads two lines
+    # (the target's record at install, the source's count at the R bookkeeping) and writes eighteen sectors over its course (word,
+    # record, two plane bits, the source's count, its onset's two stores, three later transitions of its word, queue appends)
     sparse = n_agents >= 8_000_000
-    model = ((n_agents / 8.0 if sparse else 4.0 * n_agents) + (32.0 if sparse else 4.0) * st['mean_infected'] + 8 * DAY_IMAGE_BYTES
-             + 32.0 * st['contacts_per_day'] / 50.0 + 2 * 5 * 32.0 * st['new_infections_per_day'])
+    model = ((n_agents / 8.0 if sparse else 4.0 * n_agents) + (128.0 if sparse else 4.0) * st['mean_infected'] + 8 * DAY_IMAGE_BYTES
+             + 128.0 * st['contacts_per_day'] / 50.0 + (2 * 128.0 + 18 * 32.0) * st['new_infections_per_day'])
     out = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 5),
                traffic=moved_day, scope='whole day: sum of B_alg over the timed days / wall time of the timed region (SURVEY.md 8d)',
                algorithmic_bytes_per_day=round(day_bytes, 1),
@@ -303,7 +306,8 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
                frac_meaning='vs_hot_word_streamer: the day priced at the bytes a kernel that read every agent\'s hot word would move. The engine '
                             'does not (sparse days stream one bit per agent): `moved` is the measured figure',
                moved=None, model_bytes_per_day=round(model, 1),
-               model_formula=('N/8 + 32*N_infected' if sparse else '4*N + 4*N_infected') + ' + 8 XCDs * table image + 32*contacts/50 + 320*new_infections',
+               model_formula=('N/8 + 128*N_infected' if sparse else '4*N + 4*N_infected') + ' + 8 XCDs * table image + 128*contacts/50 + 832*new_infections '
+                             '(128-byte read lines, 32-byte write sectors: profiles/pmc_calibration.json)',
                wasted=None,
                ms_per_step=round(ms_per_step, 6), kernel_us_per_day=round(ksum, 3), kernels=kernels,
                kernel_timing='HIP events (start/stop of the dispatch packet, launch stream) inside the timed region; on a profiled day '

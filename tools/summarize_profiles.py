@@ -11,9 +11,11 @@ summaries under profiles/:
                                     the libreina_hip.so they were collected on -- bench.py reports `traffic` only when
                                     that matches the binary it runs
 
-FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of a 16-B/lane stream at 64 B);
-that calibration holds for k_day's and k_open's streams; for the scattered dword reads of the other kernels it is
-an upper bound (noted in the csv)."""
+FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of a 16-B/lane stream at 64 B).  Round 6
+calibrated the other shapes (tools/ubench_pmc.hip -> profiles/pmc_calibration.json): a SCATTERED 4-byte load is one request tallied
+at 64 B as well, and two such loads 64 bytes apart in one 128-byte line are still ONE request -- every read request that leaves L2
+is a 128-byte line, so x 2 is the correction for every kernel of the day, not an upper bound; WRITE_SIZE is exact: 32 B per scattered
+store or atomic (one sector), the bytes themselves for a 16-B/lane stream."""
 import collections
 import csv
 import glob
