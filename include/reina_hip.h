@@ -481,7 +481,8 @@ int reina_read_history(reina_engine_t *e, const int32_t *history_dev, uint32_t n
 enum {
     REINA_PK_OPEN = 0, REINA_PK_TRACE1, REINA_PK_VACCINATE, REINA_PK_DAY, REINA_PK_HOSPITAL, REINA_PK_HOSP_SORT,
     REINA_PK_HOSP_WALK, REINA_PK_REMOTE, REINA_PK_INSTALL, REINA_PK_XCHG /* exact attribution: the kernels that take in exchanged records */,
-    REINA_PK_COLLECTIVE /* the in-stream collectives of a sharded day (all-reduce, all-to-alls), event pairs recorded around them */, REINA_PK_NR
+    REINA_PK_COLLECTIVE /* the in-stream collectives of a sharded day (all-reduce, all-to-alls), event pairs recorded around them */,
+    REINA_PK_SMALL_DAY /* round 6, ABI 6: the one launch of a small unsharded population's whole day (k_small_day) */, REINA_PK_NR
 };
 int reina_profile_enable(reina_engine_t *e, int enable);
 int reina_profile_read_kernels(reina_engine_t *e, double *ms_total, uint64_t *launches);

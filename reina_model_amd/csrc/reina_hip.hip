@@ -58,6 +58,7 @@ enum { EV_HOSPITALIZE = 0, EV_TO_ICU = 1, EV_RELEASE_WARD = 2, EV_RELEASE_ICU = 
 #include "k_contacts.inc"
 #include "k_remote.inc"
 #include "k_install.inc"
+#include "k_small.inc"
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -103,6 +104,8 @@ static int profiled_kind(const reina_engine *e, uint32_t day) {
 static bool kind_timed(int today, int kind) {
     if (today < 0) return false;
     if (today == REINA_PK_NR || today == kind) return true;
+    // the one launch of a small population's day (k_small_day) is timed on k_day's days and on the event walk's: twice per stride
+    if (kind == REINA_PK_SMALL_DAY) return today == REINA_PK_DAY || today == REINA_PK_HOSPITAL;
     // kernels that do not run every day are timed on k_open's days
     if (today == REINA_PK_HOSPITAL && (kind == REINA_PK_REMOTE || kind == REINA_PK_HOSP_SORT || kind == REINA_PK_HOSP_WALK || kind == REINA_PK_XCHG || kind == REINA_PK_COLLECTIVE)) return true;
     return today == REINA_PK_OPEN && (kind == REINA_PK_TRACE1 || kind == REINA_PK_VACCINATE);
@@ -153,6 +156,8 @@ static void free_engine(reina_engine *e) {
     if (e->d_params) (void)hipFree(e->d_params);
     if (e->d_tables) (void)hipFree(e->d_tables);
     if (e->d_ref) (void)hipFree(e->d_ref);
+    if (e->d_bar) (void)hipFree(e->d_bar);
+    if (e->counted_live) g_live_engines--;
     delete e;
 }
 #define HIP_CHECK_OR(x, cleanup)                                                             \
@@ -206,7 +211,7 @@ static void count_row_for(float nr_contacts, uint32_t *thr, uint8_t *guide) {
 
 extern "C" {
 
-int reina_abi_version(void) { return 5; }
+int reina_abi_version(void) { return 6; }
 
 #ifdef REINA_ABLATE
 int reina_debug_ablate(uint32_t bits) {   // diagnostic builds only (tools/ablate_day.py)
@@ -307,6 +312,13 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         if (const char *w = std::getenv("REINA_EXPORT")) e->export_by_copies = !std::strcmp(w, "memcpy");
         if (const char *w = std::getenv("REINA_OPEN_TICKETS")) e->open_tickets = std::atoi(w) != 0;   // (the tests' handle on the ticket path of a single engine)
         if (const char *w = std::getenv("REINA_IMPORTS_IN_OPEN")) e->imports_in_open = std::atoi(w) != 0;   // (the round-3 placement, for comparison)
+        // the day of a small unsharded population as ONE launch (k_small.inc): REINA_FUSED_DAY=0 keeps the three launches (the tests run
+        // every scenario family both ways), REINA_FUSED_WGS its workgroups (measurement handle; 8..64)
+        if (const char *w = std::getenv("REINA_FUSED_DAY")) e->fused_day = std::atoi(w) != 0;
+        if (const char *w = std::getenv("REINA_FUSED_WGS")) {
+            const int v = std::atoi(w);
+            if (v >= 8 && v <= 64) e->small_wgs = (uint32_t)v;
+        }
     }
     std::memset(&e->h_params, 0, sizeof(DevParams));
     std::memset(&e->h_tables, 0, sizeof(Tables));
@@ -419,6 +431,19 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     SET_LDS(k_hosp_presort, (int)walk_lds);
     SET_LDS(k_hosp_install, inst_lds);
 #undef SET_LDS
+    {
+        // the fused day of a small population: its LDS block (the stream's image or the hospital role's keys + maps, whichever is
+        // larger) beside the static LDS of the three phases' functions must fit one compute unit; its barrier counter
+        hipFuncAttributes fa;
+        HIP_CHECK_OR(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_small_day)), free_engine(e));
+        e->small_static_lds = fa.sharedSizeBytes;
+        const size_t most = 160u * 1024u > fa.sharedSizeBytes ? 160u * 1024u - fa.sharedSizeBytes : 0u;
+        HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_day), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most), free_engine(e));
+        HIP_CHECK_OR(hipMalloc(&e->d_bar, 256), free_engine(e));
+        HIP_CHECK_OR(hipMemset(e->d_bar, 0, 256), free_engine(e));
+    }
+    e->counted_live = true;
+    g_live_engines++;
     *out = e;
     return REINA_OK;
 }
@@ -894,6 +919,56 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
     return REINA_OK;
 }
 
+// The whole day of a small unsharded population as ONE launch (k_small.inc).  Every workgroup of it must be resident at once (they
+// meet at two barriers): at most one per compute unit by their LDS, `small_wgs` of them, and only while the process holds so few
+// engines that all of theirs fit the chip together (other engines' launches may run beside this one on streams of their own).
+static bool small_day_eligible(const reina_engine_t *e, const reina_day_t &dp, size_t *lds_out) {
+    if (!e->fused_day || e->cfg.n_shards != 1 || e->exact || e->coll_fn || e->h_params.hosp_parallel != 0u) return false;
+    if (e->cfg.n_agents > REINA_HOSP_SMALL_AGENTS || dp.n_vaccinations != 0u) return false;
+    if (e->day_mode != 0 || e->open_tickets || e->imports_in_open) return false;      // (the tests' handles on the three-launch forms)
+    if ((uint32_t)g_live_engines.load() * e->small_wgs > e->n_cus) return false;
+    uint32_t lds_rows = e->h_tables.n_rows > REINA_LDS_ROWS ? REINA_LDS_ROWS : e->h_tables.n_rows;
+    uint32_t lds_crows = e->h_tables.n_crows > REINA_LDS_CROWS ? REINA_LDS_CROWS : e->h_tables.n_crows;
+    if (e->lds_rows_cap && lds_rows > e->lds_rows_cap) lds_rows = e->lds_rows_cap;
+    if (e->lds_rows_cap && lds_crows > e->lds_rows_cap) lds_crows = e->lds_rows_cap;
+    const size_t lds = small_day_lds_bytes(lds_rows, lds_crows);
+    if (lds + e->small_static_lds > 160u * 1024u) return false;
+    *lds_out = lds;
+    return true;
+}
+static int launch_small_day(reina_engine_t *e, const reina_day_t &dp, size_t lds, hipStream_t s) {
+    DayGeom geo;
+    if (int rc = day_geometry(e, 1, dp, &geo)) return rc;
+    const uint32_t N = e->cfg.n_agents, W = e->small_wgs;
+    SmallGeom g;
+    std::memset(&g, 0, sizeof(g));
+    g.hist_slot = 0;
+    g.weekly_own = geo.weekly_own;
+    const bool ct = dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
+    g.mode = !e->testing_ever ? 0 : ct ? 3 : 1;   // (launch_day_open: a population this small walks level 1 in the opening)
+    g.lds_rows = e->h_tables.n_rows > REINA_LDS_ROWS ? REINA_LDS_ROWS : e->h_tables.n_rows;
+    g.lds_crows = e->h_tables.n_crows > REINA_LDS_CROWS ? REINA_LDS_CROWS : e->h_tables.n_crows;
+    if (e->lds_rows_cap && g.lds_rows > e->lds_rows_cap) g.lds_rows = e->lds_rows_cap;
+    if (e->lds_rows_cap && g.lds_crows > e->lds_rows_cap) g.lds_crows = e->lds_rows_cap;
+    g.day_flags = e->day_flags;
+    g.stream_imports = geo.stream_imports;
+    g.scan_tiles = ((N >> 2) + 127u) / 128u;
+    g.bar_base = e->bar_epoch;
+    g.bar = e->d_bar;
+    // the opening's roles: the opening workgroup, its import helpers (or the weekly imports' own workgroups), at least one for the test queue
+    const uint32_t helpers = geo.weekly_own == OPEN_WEEKLY_IN_STREAM ? 0u : geo.weekly_own > 0 ? (uint32_t)geo.weekly_own : (uint32_t)-geo.weekly_own;
+    if (W < 1u + (helpers > 1u ? helpers : 1u) + 1u || W < geo.stream_imports + 2u) {
+        g_last_error = "REINA_FUSED_WGS too small for the day's import workgroups";
+        return REINA_E_INVALID;
+    }
+    e->bar_epoch += 2u;
+    e->cur_scan_waves = (W - geo.stream_imports) * DAY_WAVES;
+    const int today = profiled_kind(e, dp.day);
+    LAUNCH_TIMED(e, today, REINA_PK_SMALL_DAY, k_small_day, dim3(W), dim3(HOSP_THREADS), lds, s, e->h_ref, dp, g);
+    HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+
 int reina_step_phase(reina_engine_t *e, const reina_day_t *day, int phase, void *stream) {
     if (!e || !day) return REINA_E_INVALID;
     if (!e->bound) return REINA_E_NOT_BOUND;
@@ -957,6 +1032,10 @@ int reina_set_alltoall(reina_engine_t *e, reina_alltoall_fn alltoall, void *comm
 }
 
 int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
+    if (e && day && e->bound) {
+        size_t lds = 0;
+        if (small_day_eligible(e, *day, &lds)) return launch_small_day(e, *day, lds, (hipStream_t)stream);
+    }
     for (int ph = 0; ph < REINA_PH_NR; ph++) {
         const int need = reina_step_phase(e, day, ph, stream);
         if (need < 0) return need;

@@ -47,11 +47,11 @@ L_POOL = 26        # control word (exact attribution): nodes of infectee_pool ha
 L_XCHG_PEAK = 27   # control word (exact attribution): the fullest any exchange segment has been (against Config.xchg_cap)
 L_HOSP_PEAK = 12   # control word: bed / ICU event count of the busiest day on which the events' order mattered
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
-ABI_VERSION = 5   # reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays; round 4: the two per-agent bit planes; round 5: exact cross-shard attribution -- exchange buffers, infectee pool, reina_step_phase)
+ABI_VERSION = 6   # (round 6: REINA_PK_SMALL_DAY, the one-launch day of a small population)  reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays; round 4: the two per-agent bit planes; round 5: exact cross-shard attribution -- exchange buffers, infectee pool, reina_step_phase)
 INLINE_INFECTEES = 8   # REINA_INLINE_INFECTEES
 COLD_WORDS = 8         # sizeof(reina_cold_t) / 4: claim (2 words), infector, n_infected, onset_days, vacc_day, first_infectee, next_sibling
 COLD_FIELDS = dict(infector=2, n_infected=3, onset_days=4, vacc_day=5, first_infectee=6, next_sibling=7)   # word of each 32-bit field
-PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg', 'collective')
+PROFILE_KINDS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg', 'collective', 'k_small_day')
 # exact cross-shard attribution (include/reina_hip.h): global ids = [shard : 4][index : 27]; the phases of a day and the
 # collectives reina_step_phase asks for
 GID_SHIFT = 27

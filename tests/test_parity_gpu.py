@@ -270,6 +270,74 @@ def test_sparse_dense_and_mixed_years_of_the_hus_population_are_identical(monkey
     assert infected.min() < int(ages.sum()) // 100 and infected.max() > int(ages.sum()) // 20
 
 
+def _kernels_of_a_run(ctx, days):
+    ctx.engine.profile_enable(1)
+    ctx.run(days)
+    k = ctx.engine.profile_read_kernels()
+    ctx.engine.profile_enable(False)
+    return {name: n for name, (ms, n) in k.items() if n}
+
+
+def test_a_small_populations_day_is_one_launch_and_the_three_launch_form_gives_the_same_days(monkeypatch):
+    """Round 6: an unsharded population of at most REINA_HOSP_SMALL_AGENTS agents runs its day as ONE launch (k_small_day:
+    opening, stream + contact sampling, installs + bed / ICU walk as phases between launch-wide barriers, k_small.inc); every other
+    test of this file that runs such a population therefore runs that kernel.  Here: (a) that it IS the kernel that runs -- and
+    that vaccination days, larger populations and REINA_FUSED_DAY=0 take the three launches --, (b) the scenario families in the
+    three-launch form against oracle B (what the default suite covered until round 5), (c) the HUS year in both forms: the
+    identical history and final state."""
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    v.update(hospital_beds=12, icu_units=2)
+    small = datasets.scaled_population(20000)
+    k = _kernels_of_a_run(simulation.make_context(v, age_counts=small, seed=1), 30)
+    assert k.get('k_small_day') == 30 and 'k_day' not in k and 'k_open' not in k and 'k_hosp_install' not in k, k
+    _, meta = load_run('mini_kitchen_s0')   # (vaccination programmes from day 12 on: those days take the launches, k_vaccinate between them)
+    ctx = simulation.make_context(variables_for(meta), age_counts=np.asarray(meta['age_counts']), seed=meta['seed'], interventions=meta['interventions'])
+    k = _kernels_of_a_run(ctx, 40)
+    assert k.get('k_small_day', 0) > 0 and k.get('k_vaccinate', 0) > 0 and k['k_small_day'] + k['k_day'] == 40 and k['k_day'] == k['k_vaccinate'], k
+    import bench
+    vv, big = bench.scaled_scenario(copy.deepcopy(VARIABLE_DEFAULTS), 3_000_000)
+    k = _kernels_of_a_run(simulation.make_context(vv, age_counts=big, seed=1), 10)
+    assert 'k_small_day' not in k and k.get('k_day') == 10, k
+    monkeypatch.setenv('REINA_FUSED_DAY', '0')
+    k = _kernels_of_a_run(simulation.make_context(v, age_counts=small, seed=1), 30)
+    assert 'k_small_day' not in k and k.get('k_day') == 30 and k.get('k_open') == 30 and k.get('k_hosp_install') == 30, k
+    # (b) three launches, against oracle B
+    _run_and_compare(v, small, 2, 200)
+    for name in ('mini_kitchen_s3', 'mini_imports_s1', 'mini_initial_s1', 'turku_astra-zeneca_s1'):
+        _, meta = load_run(name)
+        _run_and_compare(variables_for(meta), np.asarray(meta['age_counts']), meta['seed'], meta['days'], interventions=meta['interventions'],
+                         ipc=meta.get('ipc'), chunk=100)
+    for case in (1, 4, 9, 12):
+        rng = np.random.default_rng(1000 + case)
+        vv, ages, days, ivs, ipc = _random_scenario(rng)
+        _run_and_compare(vv, ages, int(rng.integers(0, 2 ** 31)), days, interventions=ivs, chunk=40, ipc=ipc)
+    # (c) the HUS year (BASELINE configs[1]) either way
+    hus = datasets.get_population_for_area()
+    runs = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('REINA_FUSED_DAY', fused)
+        ctx = simulation.make_context(copy.deepcopy(VARIABLE_DEFAULTS), age_counts=hus, seed=4)
+        hist = ctx.run(365)
+        _assert_bit_planes(ctx)
+        t = ctx.engine.tensors
+        runs[fused] = (hist, [ctx.engine.alloc.to_host(t[k_]).copy() for k_ in ('hot', 'infector', 'n_infected', 'onset_days')])
+        del ctx
+    assert np.array_equal(runs['1'][0], runs['0'][0])
+    for a, b in zip(runs['1'][1], runs['0'][1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize('wgs', ['8', '19', '64'])
+def test_the_one_launch_day_on_other_numbers_of_workgroups(wgs, monkeypatch):
+    """REINA_FUSED_WGS: the launch's workgroups (default 32) -- the opening's roles, the stream's slices and the installs' units
+    are dealt out over whatever number there is; 19 is no multiple of anything"""
+    monkeypatch.setenv('REINA_FUSED_WGS', wgs)
+    _, meta = load_run('mini_kitchen_s3')
+    _run_and_compare(variables_for(meta), np.asarray(meta['age_counts']), meta['seed'], meta['days'], interventions=meta['interventions'])
+    v = copy.deepcopy(VARIABLE_DEFAULTS)
+    _run_and_compare(v, datasets.scaled_population(300000), 3, 250, chunk=125)   # (the default scenario's weekly imports from July on)
+
+
 def test_eager_iterate_equals_batched_run():
     """iterate()+generate_state() per day (the reference's calling pattern) == run(days)"""
     v = copy.deepcopy(VARIABLE_DEFAULTS)
