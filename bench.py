@@ -55,7 +55,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 HUS_AGENTS = 1685983
-DAY_KERNELS = ('k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg', 'collective')
+DAY_KERNELS = ('k_small_day', 'k_open', 'k_test_trace1', 'k_vaccinate', 'k_day', 'k_hospital', 'k_hosp_sort', 'k_hosp_walk', 'k_remote', 'k_hosp_install', 'k_xchg', 'collective')
 # the chip's RANDOM-ACCESS rates, G accesses/s (tools/ubench_random.hip, profiles/r05_evidence/ubench_random.txt: independent of the requests
 # in flight per lane and of the waves per CU -- throughput limits): what bounds k_hosp_install, whose bytes are nothing
 RANDOM_RATES = dict(load=50.0, store=23.0, atomic=18.0, atomic_cached=26.0)
@@ -244,6 +244,9 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
     alg = {   # algorithmic bytes per launch of the kernels that own a term of B_alg
         'k_day': 4.0 * n_agents + 4.0 * st['infected_on_scan_days'] + 4.0 * st['contacts_on_scan_days'],
         'k_hosp_install': 12.0 * st['new_infections_per_day'],
+        # (round 6: a small unsharded population's whole day is ONE launch -- opening, stream, installs between launch-wide barriers --:
+        # its algorithmic bytes are the day's)
+        'k_small_day': day_bytes,
     }
     moved_day, moved_k, util, note = (None, {}, {}, None)
     trace = {}
@@ -285,7 +288,7 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
             ent['valu'] = {'mean_day': util[k].get('valu_mean_day'), 'peak_day': util[k].get('valu_peak_day')}
             ent['waiting'] = {'mean_day': util[k].get('waiting_mean_day'), 'peak_day': util[k].get('waiting_peak_day')}
         kernels[k] = ent
-    every_day = [k for k in ('k_open', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install', 'k_hosp_sort', 'k_hosp_walk', 'k_xchg') if k in kernels]
+    every_day = [k for k in ('k_small_day', 'k_open', 'k_day', 'k_hospital', 'k_remote', 'k_hosp_install', 'k_hosp_sort', 'k_hosp_walk', 'k_xchg') if k in kernels]
     ksum = sum(kernels[k]['avg_launch_us'] for k in every_day)
     for k in every_day:
         kernels[k]['share_of_kernel_time'] = round(kernels[k]['avg_launch_us'] / ksum, 4) if ksum else None
@@ -334,8 +337,11 @@ def roofline_obj(n_agents, res, steps, stride, traffic_key=None):
         'peak_day': 'valu issue in k_day (contact sampling: Philox + table search per contact)' + (
             ', %.2f of the chip\'s VALU issue slots over the launch' % vd['valu_peak_day'] if vd.get('valu_peak_day') else '') +
             '; scattered-access latency in k_hosp_install'}
-    if 'k_day' in kernels:
-        out['dominant_kernel'] = dict(name='k_day', **kernels['k_day'])
+    dom = 'k_day' if 'k_day' in kernels and kernels['k_day']['avg_launch_us'] * kernels['k_day']['timed_launches'] >= \
+        kernels.get('k_small_day', {}).get('avg_launch_us', 0.0) * kernels.get('k_small_day', {}).get('timed_launches', 0) else \
+        'k_small_day' if 'k_small_day' in kernels else None
+    if dom:
+        out['dominant_kernel'] = dict(name=dom, **kernels[dom])
     return out
 
 
@@ -372,7 +378,7 @@ def _roofline_brief(r):
     out['kernel_us_per_day'] = r.get('kernel_us_per_day')
     if 'kernel_us_per_day_trace' in r:
         out['kernel_us_per_day_trace'] = r['kernel_us_per_day_trace']
-    out['dominant_kernel'] = 'k_day'
+    out['dominant_kernel'] = (r.get('dominant_kernel') or {}).get('name')
     out['kernels'] = {k: _kernel_brief(r, k) for k in (r.get('kernels') or {})}
     return out
 
@@ -400,6 +406,9 @@ def compact_line(out):
                       'kernel_us_per_day': r.get('kernel_us_per_day_trace', r.get('kernel_us_per_day')),
                       'k_day': _kernel_brief(r, 'k_day'), 'k_hosp_install': _kernel_brief(r, 'k_hosp_install'),
                       'k_open_us': ((r.get('kernels') or {}).get('k_open') or {}).get('avg_launch_us')}
+        if 'k_small_day' in (r.get('kernels') or {}):
+            sizes[key]['k_small_day'] = _kernel_brief(r, 'k_small_day')
+        sizes[key] = {k: v for k, v in sizes[key].items() if v is not None}
     if sizes:
         rl['full_scenario_365d'] = sizes
     line['roofline'] = rl

@@ -75,7 +75,7 @@ static int age_of(const Par *e, uint32_t i) {
     return lo;
 }
 
-int par_abi_version(void) { return 5; }
+int par_abi_version(void) { return 6; }
 
 /* ---------------------------------------------------------------- exact attribution: ids and exchange segments */
 static int32_t gid_of(const Par *e, uint32_t i) { return (int32_t)(e->gid_base | i); }

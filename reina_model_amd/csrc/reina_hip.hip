@@ -59,6 +59,7 @@ enum { EV_HOSPITALIZE = 0, EV_TO_ICU = 1, EV_RELEASE_WARD = 2, EV_RELEASE_ICU = 
 #include "k_remote.inc"
 #include "k_install.inc"
 #include "k_small.inc"
+#define SMALL_MAX_DAYS 64u   // days of one k_small_days launch (the records' device buffer)
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -133,13 +134,17 @@ static bool kind_timed(int today, int kind) {
 
 static void resolve_profile(reina_engine *e) {
     for (int k = 0; k < REINA_PK_NR; k++) {
+        size_t idx = 0;
         for (auto &p : e->kpairs[k]) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, e->ev_pool[p.first], e->ev_pool[p.second]) == hipSuccess) {
                 e->k_ms[k] += ms;
-                e->k_launches[k]++;
+                // (a k_small_days launch runs a stretch of days: the kind counts DAYS, so that ms / count is a day's time like the others')
+                e->k_launches[k] += k == REINA_PK_SMALL_DAY && idx < e->small_pair_days.size() ? e->small_pair_days[idx] : 1u;
             }
+            idx++;
         }
+        if (k == REINA_PK_SMALL_DAY) e->small_pair_days.clear();
         e->kpairs[k].clear();
     }
     e->ev_used = 0;
@@ -157,6 +162,12 @@ static void free_engine(reina_engine *e) {
     if (e->d_tables) (void)hipFree(e->d_tables);
     if (e->d_ref) (void)hipFree(e->d_ref);
     if (e->d_bar) (void)hipFree(e->d_bar);
+    if (e->d_days) (void)hipFree(e->d_days);
+    for (size_t k = 0; k < e->days_stage.size(); k++) {
+        (void)hipEventSynchronize(e->days_stage_ev[k]);
+        (void)hipEventDestroy(e->days_stage_ev[k]);
+        (void)hipHostFree(e->days_stage[k]);
+    }
     if (e->counted_live) g_live_engines--;
     delete e;
 }
@@ -435,12 +446,13 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         // the fused day of a small population: its LDS block (the stream's image or the hospital role's keys + maps, whichever is
         // larger) beside the static LDS of the three phases' functions must fit one compute unit; its barrier counter
         hipFuncAttributes fa;
-        HIP_CHECK_OR(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_small_day)), free_engine(e));
+        HIP_CHECK_OR(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_small_days)), free_engine(e));
         e->small_static_lds = fa.sharedSizeBytes;
         const size_t most = 160u * 1024u > fa.sharedSizeBytes ? 160u * 1024u - fa.sharedSizeBytes : 0u;
-        HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_day), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most), free_engine(e));
+        HIP_CHECK_OR(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_days), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most), free_engine(e));
         HIP_CHECK_OR(hipMalloc(&e->d_bar, 256), free_engine(e));
         HIP_CHECK_OR(hipMemset(e->d_bar, 0, 256), free_engine(e));
+        HIP_CHECK_OR(hipMalloc(&e->d_days, sizeof(SmallDayRec) * SMALL_MAX_DAYS), free_engine(e));
     }
     e->counted_live = true;
     g_live_engines++;
@@ -919,53 +931,125 @@ static int launch_day_end(reina_engine_t *e, const MemberRef *refs, uint32_t K, 
     return REINA_OK;
 }
 
-// The whole day of a small unsharded population as ONE launch (k_small.inc).  Every workgroup of it must be resident at once (they
-// meet at two barriers): at most one per compute unit by their LDS, `small_wgs` of them, and only while the process holds so few
-// engines that all of theirs fit the chip together (other engines' launches may run beside this one on streams of their own).
-static bool small_day_eligible(const reina_engine_t *e, const reina_day_t &dp, size_t *lds_out) {
+// A stretch of days of a small unsharded population as ONE launch (k_small.inc).  Every workgroup of it must be resident at once
+// (they meet at three barriers a day): at most one per compute unit by their LDS, `small_wgs` of them, and only while the process
+// holds so few engines that all of theirs fit the chip together (other engines' launches may run beside this one on streams of
+// their own).  A day qualifies when nothing in it needs another launch shape: no vaccination programme, at most one workgroup's
+// worth of weekly imports, import helpers and one test-queue role within the launch's workgroups.
+static bool small_days_engine_ok(const reina_engine_t *e) {
     if (!e->fused_day || e->cfg.n_shards != 1 || e->exact || e->coll_fn || e->h_params.hosp_parallel != 0u) return false;
-    if (e->cfg.n_agents > REINA_HOSP_SMALL_AGENTS || dp.n_vaccinations != 0u) return false;
+    if (e->cfg.n_agents > REINA_HOSP_SMALL_AGENTS) return false;
     if (e->day_mode != 0 || e->open_tickets || e->imports_in_open) return false;      // (the tests' handles on the three-launch forms)
     if ((uint32_t)g_live_engines.load() * e->small_wgs > e->n_cus) return false;
-    uint32_t lds_rows = e->h_tables.n_rows > REINA_LDS_ROWS ? REINA_LDS_ROWS : e->h_tables.n_rows;
-    uint32_t lds_crows = e->h_tables.n_crows > REINA_LDS_CROWS ? REINA_LDS_CROWS : e->h_tables.n_crows;
-    if (e->lds_rows_cap && lds_rows > e->lds_rows_cap) lds_rows = e->lds_rows_cap;
-    if (e->lds_rows_cap && lds_crows > e->lds_rows_cap) lds_crows = e->lds_rows_cap;
-    const size_t lds = small_day_lds_bytes(lds_rows, lds_crows);
-    if (lds + e->small_static_lds > 160u * 1024u) return false;
-    *lds_out = lds;
+    return SMALL_TAIL_BYTES + e->small_static_lds <= 160u * 1024u;
+}
+// the record of one day, or false: the day takes the three launches
+static bool small_day_record(reina_engine_t *e, const reina_day_t &dp, SmallDayRec *rec) {
+    if (dp.n_vaccinations != 0u) return false;
+    DayGeom geo;
+    if (day_geometry(e, 1, dp, &geo) != REINA_OK) return false;
+    const uint32_t W = e->small_wgs;
+    const uint32_t helpers = geo.weekly_own == OPEN_WEEKLY_IN_STREAM ? 0u : geo.weekly_own > 0 ? (uint32_t)geo.weekly_own : (uint32_t)-geo.weekly_own;
+    if (W < 1u + (helpers > 1u ? helpers : 1u) + 1u || geo.stream_imports > 1u) return false;
+    std::memset(rec, 0, sizeof(*rec));
+    rec->dp = dp;
+    rec->weekly_own = geo.weekly_own;
+    const bool ct = dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
+    rec->mode = !e->testing_ever ? 0 : ct ? 3 : 1;   // (launch_day_open: a population this small walks level 1 in the opening)
+    rec->stream_imports = geo.stream_imports;
     return true;
 }
-static int launch_small_day(reina_engine_t *e, const reina_day_t &dp, size_t lds, hipStream_t s) {
-    DayGeom geo;
-    if (int rc = day_geometry(e, 1, dp, &geo)) return rc;
+static int launch_small_days(reina_engine_t *e, const SmallDayRec *recs, uint32_t n, hipStream_t s) {
+    // the records travel like the tables: a pinned slot the host fills, a copy kernel in the day stream (reina_upload_contact_tables)
+    size_t slot = e->days_stage.size();
+    for (size_t k = 0; k < e->days_stage.size(); k++)
+        if (hipEventQuery(e->days_stage_ev[k]) == hipSuccess) {
+            slot = k;
+            break;
+        }
+    if (slot == e->days_stage.size()) {
+        if (e->days_stage.size() < reina_engine::MAX_STAGES) {
+            SmallDayRec *st = nullptr;
+            hipEvent_t ev;
+            HIP_CHECK(hipHostMalloc((void **)&st, sizeof(SmallDayRec) * SMALL_MAX_DAYS, hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->days_stage.push_back(st);
+            e->days_stage_ev.push_back(ev);
+        } else {
+            slot = 0;
+            HIP_CHECK(hipEventSynchronize(e->days_stage_ev[0]));
+        }
+    }
+    std::memcpy(e->days_stage[slot], recs, sizeof(SmallDayRec) * n);
+    void *dsrc = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&dsrc, e->days_stage[slot], 0));
+    UploadSegs none;
+    std::memset(&none, 0, sizeof(none));
+    const uint32_t words = (uint32_t)(sizeof(SmallDayRec) * n / 4);
+    hipLaunchKernelGGL(k_upload, dim3(words / 256u + 1u < 64u ? words / 256u + 1u : 64u), dim3(256), 0, s, reinterpret_cast<uint32_t *>(e->d_days),
+                       reinterpret_cast<const uint32_t *>(dsrc), words, (uint32_t *)nullptr, (const uint32_t *)nullptr, none);
+    HIP_CHECK(hipEventRecord(e->days_stage_ev[slot], s));
     const uint32_t N = e->cfg.n_agents, W = e->small_wgs;
     SmallGeom g;
     std::memset(&g, 0, sizeof(g));
-    g.hist_slot = 0;
-    g.weekly_own = geo.weekly_own;
-    const bool ct = dp.testing_mode == RT_ALL_WITH_SYMPTOMS_CT;
-    g.mode = !e->testing_ever ? 0 : ct ? 3 : 1;   // (launch_day_open: a population this small walks level 1 in the opening)
+    g.n_days = n;
     g.lds_rows = e->h_tables.n_rows > REINA_LDS_ROWS ? REINA_LDS_ROWS : e->h_tables.n_rows;
     g.lds_crows = e->h_tables.n_crows > REINA_LDS_CROWS ? REINA_LDS_CROWS : e->h_tables.n_crows;
     if (e->lds_rows_cap && g.lds_rows > e->lds_rows_cap) g.lds_rows = e->lds_rows_cap;
     if (e->lds_rows_cap && g.lds_crows > e->lds_rows_cap) g.lds_crows = e->lds_rows_cap;
     g.day_flags = e->day_flags;
-    g.stream_imports = geo.stream_imports;
     g.scan_tiles = ((N >> 2) + 127u) / 128u;
     g.bar_base = e->bar_epoch;
     g.bar = e->d_bar;
-    // the opening's roles: the opening workgroup, its import helpers (or the weekly imports' own workgroups), at least one for the test queue
-    const uint32_t helpers = geo.weekly_own == OPEN_WEEKLY_IN_STREAM ? 0u : geo.weekly_own > 0 ? (uint32_t)geo.weekly_own : (uint32_t)-geo.weekly_own;
-    if (W < 1u + (helpers > 1u ? helpers : 1u) + 1u || W < geo.stream_imports + 2u) {
-        g_last_error = "REINA_FUSED_WGS too small for the day's import workgroups";
-        return REINA_E_INVALID;
+    g.days = e->d_days;
+    e->bar_epoch += SMALL_BARRIERS_PER_DAY * n;
+    e->cur_scan_waves = (W - 1u) * DAY_WAVES;
+    // (timed as a whole on the stretches that begin on one of the two profiled phases; the kind's "launches" count DAYS: its mean is per day)
+    const int today = profiled_kind(e, recs[0].dp.day);
+    size_t ev_a, ev_b;
+    if (kind_timed(today, REINA_PK_SMALL_DAY) && take_event_pair(e, &ev_a, &ev_b)) {
+        hipExtLaunchKernelGGL(k_small_days, dim3(W), dim3(HOSP_THREADS), SMALL_TAIL_BYTES, s, e->ev_pool[ev_a], e->ev_pool[ev_b], 0, e->h_ref, g);
+        e->kpairs[REINA_PK_SMALL_DAY].emplace_back(ev_a, ev_b);
+        e->small_pair_days.push_back(n);
+    } else {
+        hipLaunchKernelGGL(k_small_days, dim3(W), dim3(HOSP_THREADS), SMALL_TAIL_BYTES, s, e->h_ref, g);
     }
-    e->bar_epoch += 2u;
-    e->cur_scan_waves = (W - geo.stream_imports) * DAY_WAVES;
-    const int today = profiled_kind(e, dp.day);
-    LAUNCH_TIMED(e, today, REINA_PK_SMALL_DAY, k_small_day, dim3(W), dim3(HOSP_THREADS), lds, s, e->h_ref, dp, g);
     HIP_CHECK(hipGetLastError());
+    return REINA_OK;
+}
+// days[0 .. n): stretches of qualifying days (at least two: a single day is faster as three launches) as one launch each, the rest day by day
+static int run_days_small(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, int32_t *history_base, hipStream_t s) {
+    std::vector<SmallDayRec> recs;
+    recs.reserve(SMALL_MAX_DAYS);
+    uint32_t k = 0;
+    while (k < n_days) {
+        recs.clear();
+        uint32_t m = 0;
+        while (k + m < n_days && m < SMALL_MAX_DAYS) {
+            reina_day_t d = days[k + m];
+            if (history_base) d.history_row = history_base + (size_t)(k + m) * REINA_COUNTER_WORDS;
+            SmallDayRec r;
+            if (!small_day_record(e, d, &r)) break;
+            recs.push_back(r);
+            m++;
+        }
+        if (m >= 2u) {
+            if (int rc = launch_small_days(e, recs.data(), m, s)) return rc;
+            k += m;
+            continue;
+        }
+        // (one qualifying day between two that do not, or none: the launches)
+        const uint32_t take = m ? m : 1u;
+        for (uint32_t q = 0; q < take; q++) {
+            reina_day_t d = days[k + q];
+            if (history_base) d.history_row = history_base + (size_t)(k + q) * REINA_COUNTER_WORDS;
+            for (int ph = 0; ph < REINA_PH_NR; ph++) {
+                const int need = reina_step_phase(e, &d, ph, s);
+                if (need < 0) return need;
+            }
+        }
+        k += take;
+    }
     return REINA_OK;
 }
 
@@ -1032,10 +1116,6 @@ int reina_set_alltoall(reina_engine_t *e, reina_alltoall_fn alltoall, void *comm
 }
 
 int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
-    if (e && day && e->bound) {
-        size_t lds = 0;
-        if (small_day_eligible(e, *day, &lds)) return launch_small_day(e, *day, lds, (hipStream_t)stream);
-    }
     for (int ph = 0; ph < REINA_PH_NR; ph++) {
         const int need = reina_step_phase(e, day, ph, stream);
         if (need < 0) return need;
@@ -1068,6 +1148,7 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
 }
 
 int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, void *stream) {
+    if (e && days && e->bound && n_days >= 2u && small_days_engine_ok(e)) return run_days_small(e, days, n_days, nullptr, (hipStream_t)stream);
     for (uint32_t k = 0; k < n_days; k++) {
         int rc = reina_step_day(e, &days[k], stream);
         if (rc) return rc;
@@ -1076,6 +1157,7 @@ int reina_run_days(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, 
 }
 
 int reina_run_days_hist(reina_engine_t *e, const reina_day_t *days, uint32_t n_days, int32_t *history_base, void *stream) {
+    if (e && days && e->bound && n_days >= 2u && small_days_engine_ok(e)) return run_days_small(e, days, n_days, history_base, (hipStream_t)stream);
     for (uint32_t k = 0; k < n_days; k++) {
         reina_day_t d = days[k];
         d.history_row = history_base ? history_base + (size_t)k * REINA_COUNTER_WORDS : nullptr;
