@@ -323,8 +323,9 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
         if (const char *w = std::getenv("REINA_EXPORT")) e->export_by_copies = !std::strcmp(w, "memcpy");
         if (const char *w = std::getenv("REINA_OPEN_TICKETS")) e->open_tickets = std::atoi(w) != 0;   // (the tests' handle on the ticket path of a single engine)
         if (const char *w = std::getenv("REINA_IMPORTS_IN_OPEN")) e->imports_in_open = std::atoi(w) != 0;   // (the round-3 placement, for comparison)
-        // the day of a small unsharded population as ONE launch (k_small.inc): REINA_FUSED_DAY=0 keeps the three launches (the tests run
-        // every scenario family both ways), REINA_FUSED_WGS its workgroups (measurement handle; 8..64)
+        // stretches of days of a small unsharded population as ONE launch (k_small.inc): REINA_FUSED_DAY=1 switches it on (off by
+        // default: measured slower than the three launches a day; the tests run scenario families both ways), REINA_FUSED_WGS its
+        // workgroups (measurement handle; 8..64)
         if (const char *w = std::getenv("REINA_FUSED_DAY")) e->fused_day = std::atoi(w) != 0;
         if (const char *w = std::getenv("REINA_FUSED_WGS")) {
             const int v = std::atoi(w);
