@@ -600,7 +600,7 @@ def ensemble_line(seeds, days, device, dist=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ensemble.run_group_plan(members, plan)
+    hist = ensemble.run_group_plan(members, plan)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -611,7 +611,24 @@ def ensemble_line(seeds, days, device, dist=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n = int(ages.sum())
-    return dict(workload='%d seeds x HUS %d agents x %d days per GPU, one engine group per GPU (config 5: replicas only)' % (seeds, n, days),
+    # the group's step against HBM, like a single population's day: B_alg summed over the members (means over members and days of
+    # infected agents, contacts and new infections from their histories) / the wall time of a group step; `traffic`: PMC bytes per
+    # group step when profiles/traffic.json holds a pass over this very command on this binary (key ensemble_<seeds>)
+    import numpy as np
+    A = _eng.MAX_AGES
+    i_inf, i_new = _eng.C_NAMES.index('infected'), _eng.C_NAMES.index('new_infections')
+    mean_inf = float(hist[:, :, i_inf * A:(i_inf + 1) * A].sum(axis=2).mean())
+    mean_new = float(hist[:, 1:, i_new * A:(i_new + 1) * A].sum(axis=2).mean())
+    mean_con = float(hist[:, 1:, _eng.C_NR * A + _eng.S_EXPOSED_PER_DAY].mean())
+    step_bytes = seeds * (4.0 * n + 4.0 * mean_inf + 4.0 * mean_con + 12.0 * mean_new)
+    step_s = dt / days
+    moved, _, _, note = traffic_for('ensemble_%d' % seeds)
+    roof = dict(bound='hbm', achieved=round(step_bytes / step_s / 1e9, 2), peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=round(step_bytes / step_s / 1e9 / HBM_PEAK_GBS, 5), traffic=moved,
+                moved_frac=round(moved / step_s / 1e9 / HBM_PEAK_GBS, 5) if moved else None,
+                algorithmic_bytes_per_group_step=round(step_bytes, 1), scope='one step of the whole group (%d member-days): B_alg summed over the members / wall time' % seeds,
+                traffic_note=note)
+    return dict(workload='%d seeds x HUS %d agents x %d days per GPU, one engine group per GPU (config 5: replicas only)' % (seeds, n, days), roofline=roof,
                 value=round(world * seeds * n * days / dt, 1), unit='agent-days/s', ms_per_step=round(dt * 1000 / days, 6),
                 members_per_gpu=seeds, n_gpus=world,
                 note='timed: group construction, every launch of the year, the read-back of all members\' history rows and final counters; the page-locked block the history comes back through was requested once before the timed region and a two-member group ran five days first (a process\'s first ensemble pays some 30 ms more: page-locking, the kernels\' first launches)',

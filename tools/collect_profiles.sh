@@ -21,6 +21,10 @@ done
 W="--no-cpu --no-sizes --no-ensemble --steps 20 --warmup 5 --preheat-days 0"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch_husw -- python3 $R/bench.py $W > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write_husw -- python3 $R/bench.py $W > /dev/null 2>&1
+# the 128-member ensemble (BASELINE config 5): the bytes of a group step -- the same bench command with only the ensemble beside the window
+E="--no-cpu --no-sizes --steps 20 --warmup 5 --preheat-days 0"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch_ens -- python3 $R/bench.py $E > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write_ens -- python3 $R/bench.py $E > /dev/null 2>&1
 for cfg in "hus:" "50m:--agents 50000000" "100m:--agents 100000000" "200m:--agents 200000000"; do
   name=${cfg%%:*}; args=${cfg#*:}
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/${TAG}_sq1_$name -- python3 $R/bench.py $COMMON $args > /dev/null 2>&1

@@ -148,6 +148,32 @@ for cfg, key in (('hus', 'hus'), ('husw', 'hus_window'), ('50m', '50000000'), ('
                     v = np.array(sq[n][c])
                     w.writerow([n, c, len(v), '%.5g' % v.mean(), '%.5g' % v[int(len(v) * 0.05)], '%.5g' % v.max()])
 
+# the ensemble (BASELINE config 5): bytes per GROUP STEP of the 128-member group -- the group kernels' dispatches of the full-size
+# group (the largest grid of each kernel: a two-member warm-up group runs the same kernels first), 365 steps
+ens_rows, ens_tot, ens_ok = [['kernel', 'counter', 'dispatches', 'mean_KB_per_group_step', 'HBM_bytes_per_group_step (FETCH x2)']], 0.0, True
+for kind, cname, mult in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE', 1.0)):
+    f = newest(os.path.join(G, '%s_%s_ens' % (tag, kind), '*', '*counter_collection.csv'))
+    if not f:
+        ens_ok = False
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        n = r['Kernel_Name'].replace('void ', '')
+        if n.startswith('k_') and '<true' in n and r['Counter_Name'] == cname:
+            agg[n.split('(')[0]].append((int(r['Grid_Size']), float(r['Counter_Value'])))
+    for n in sorted(agg):
+        big = max(g for g, _ in agg[n])
+        v = np.array([x for g, x in agg[n] if g == big])
+        steps = 365.0
+        b = mult * v.sum() * 1024 / steps
+        ens_rows.append([n, cname, len(v), round(v.sum() / steps, 2), int(round(b))])
+        ens_tot += b
+if ens_ok and ens_tot:
+    ens_rows.append(['ALL', 'FETCH_SIZE x2 + WRITE_SIZE', '', '', int(round(ens_tot))])
+    per_day['ensemble_128'] = int(round(ens_tot))
+    with open(os.path.join(P, '%s_pmc_hbm_ensemble128.csv' % tag), 'w') as f:
+        csv.writer(f).writerows(ens_rows)
+
 sha_f = os.path.join(G, '%s_lib_sha256.txt' % tag)
 if per_day and os.path.exists(sha_f):
     try:
