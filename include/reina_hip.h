@@ -474,7 +474,8 @@ int reina_read_history(reina_engine_t *e, const int32_t *history_dev, uint32_t n
  * turns -- k_day (the stream + contact sampling) on days with day % k == 0, k_open (+ the occasional kernels:
  * level-1 tracing, vaccination) at k/4, the event-walk launches (a sharded population's, a large population's
  * k_hosp_sort / k_hosp_walk) and the cross-shard realisation at k/2, k_hosp_install at 3k/4 -- so that the cost of timestamped dispatches (a few
- * microseconds each, which matters when a whole day takes 40) stays small.
+ * microseconds each, which matters when a whole day takes 40) stays small; k <= -4: stride -k, and ONLY k_day is timed (the
+ * dominant kernel of a short window: a third of the timestamped dispatches).
  * reina_profile_read_kernels: summed milliseconds and launch counts per kind since the last read, arrays of
  * REINA_PK_NR; synchronises the device.  reina_profile_read: the k_day pair of those numbers and the sum
  * over all kinds. */

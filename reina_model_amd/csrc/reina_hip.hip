@@ -97,6 +97,7 @@ static int profiled_kind(const reina_engine *e, uint32_t day) {
     const uint32_t ph = day % stride;
     // the four kernels of every day at evenly spaced phases; the occasional ones ride with k_open's phase
     if (ph == 0) return REINA_PK_DAY;
+    if (e->profile_day_only) return -1;   // (enable < 0: only the dominant kernel carries timestamps -- a third of the instrument's cost)
     if (ph == stride / 4) return REINA_PK_OPEN;
     if (ph == stride / 2) return REINA_PK_HOSPITAL;
     if (ph == stride / 2 + stride / 4) return REINA_PK_INSTALL;
@@ -1338,6 +1339,8 @@ int reina_read_history(reina_engine_t *e, const int32_t *history_dev, uint32_t n
 int reina_profile_enable(reina_engine_t *e, int enable) {
     if (!e) return REINA_E_INVALID;
     e->profile = enable != 0;
+    e->profile_day_only = enable < 0;      // -k: stride k, and only k_day (the stream + contact sampling) is timed
+    if (enable < 0) enable = -enable;
     e->profile_stride = enable > 1 ? (uint32_t)(enable < 4 ? 4 : enable) : 1u;   // (four kinds take turns: stride >= 4)
     // create timing events up front: hipEventCreate inside a timed region costs microseconds each
     while (e->profile && e->ev_pool.size() < 1024) {

@@ -498,7 +498,7 @@ class Engine:
         return out
 
     def profile_enable(self, on=True):
-        """on: False/0 off, True/1 every day, k > 1 every k-th day (day % k == 0)"""
+        """on: False/0 off, True/1 every day, k > 1 every k-th day (day % k == 0); -k: stride k and only k_day is timed"""
         self._check(self.f['profile_enable'](self._h, int(on)), 'profile_enable')
 
     def profile_read(self):

@@ -243,10 +243,12 @@ class Context:
         # cross-shard infector links: 'exact' (global ids, contact / feedback / tracing records exchanged
         # through all-to-all segments -- the true infector as in the reference, main.pyx:219-233) or 'mirror' (stand-in
         # infectors, one all-reduce per day; sharding.py).  The comm object says which; exact unless told otherwise.
-        self.attribution = getattr(comm, 'attribution', 'exact') if self.n_shards > 1 else 'none'
+        from .sharding import DEFAULT_ATTRIBUTION
+        self.attribution = getattr(comm, 'attribution', DEFAULT_ATTRIBUTION) if self.n_shards > 1 else 'none'
         if self.attribution not in ('exact', 'mirror', 'none'):
             raise ValueError("comm.attribution must be 'exact' or 'mirror'")
-        if self.attribution == 'exact' and not (hasattr(comm, 'all_to_all') or getattr(self._direct, 'a2a_ptr', None)):
+        # (shards stepped together in one process -- sharding.InProcessComm, `members` -- are exchanged by their driver)
+        if self.attribution == 'exact' and not (hasattr(comm, 'all_to_all') or hasattr(comm, 'members') or getattr(self._direct, 'a2a_ptr', None)):
             # (a comm object written for the one all-reduce of rounds 1-4 has no `attribution` and would be switched to exact
             # attribution silently, to fail with AttributeError on the first stepped day: round-5 advisor)
             raise TypeError("exact attribution (sharding.DEFAULT_ATTRIBUTION; SURVEY 8 f-4) exchanges records: the comm object "

@@ -117,12 +117,21 @@ class DirectRccl:
             self.comm = None
 
 
+# Cross-shard infector links: the ONE place the default is decided.  'exact': the true
+# infector of every cross-shard infection, as in the reference (main.pyx:219-233) -- contact / feedback / tracing records through
+# all-to-all segments, three to five collectives a day; 'mirror': stand-in infectors, ONE all-reduce a day (north_star's exchange).
+# The library's comm objects default to it; model.Context reads the comm's `attribution` (a comm object without one gets it too and
+# must then provide all_to_all: checked at construction); bench.py --gpus N measures 'mirror' unless told otherwise and labels
+# its line with the mode it ran (config.attribution) -- the one-collective day is what BASELINE.json's north_star describes.
+DEFAULT_ATTRIBUTION = 'exact'
+
+
 class TorchComm:
     """torch.distributed wrapper: `nccl` (= RCCL on ROCm) for HBM tensors, `gloo` for host arrays.
     With the nccl backend the per-day exchange bypasses torch (DirectRccl, REINA_DIRECT_RCCL=0 turns
     that off); counter reductions at export time keep using torch.distributed."""
 
-    def __init__(self, group=None, attribution='exact'):
+    def __init__(self, group=None, attribution=DEFAULT_ATTRIBUTION):
         import torch
         import torch.distributed as dist
         self.attribution = attribution
@@ -192,7 +201,7 @@ class InProcessComm:
     """All G shards live in ONE process and are stepped in lock-step by `step_shards_together`
     (tests; single-GPU emulation of a sharded run).  Collectives are plain sums over the members."""
 
-    def __init__(self, rank, world, members, attribution='exact'):
+    def __init__(self, rank, world, members, attribution=DEFAULT_ATTRIBUTION):
         self.rank = rank
         self.world = world
         self.members = members  # shared list of Contexts, filled by the driver
