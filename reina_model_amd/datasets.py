@@ -19,7 +19,7 @@ _DATA = os.path.join(_DATA_DIR, 'fi_hus.json')
 # area name (variables['area_name']) -> bundled file: the age histogram the reference computes from data/005_11re_2019.csv
 # (a municipality, or the municipalities of a hospital district: calc/datasets.py:48-61) and the rows of the area's case file
 # (AREA_CASEFILES, calc/datasets.py:82-86), recorded by tests/golden/make_golden.py / make_turku.py
-_AREAS = {'HUS': 'fi_hus.json', 'Turku': 'fi_turku.json'}
+_AREAS = {'HUS': 'fi_hus.json', 'Turku': 'fi_turku.json', 'Varsinais-Suomi': 'fi_varsinais-suomi.json'}
 _cache = {}
 
 

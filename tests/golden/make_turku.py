@@ -137,6 +137,16 @@ def gen_inputs():
                        variable_defaults={k: v[k] for k in v if k not in ('scenarios', 'area_name_long')},
                        age_counts=pkg['age_counts']), f)
     print('fi_turku.json: N=%d, %d case rows (%s .. %s)' % (ages.sum(), len(rows), rows[0][0], rows[-1][0]))
+    # the third area the reference has a case file for (AREA_CASEFILES, calc/datasets.py:82-86): a hospital district, its population
+    # the sum over its member municipalities (get_population_for_area's other branch, :55-58)
+    vs = dict(v, area_name='Varsinais-Suomi')
+    ages_vs = ds.get_population_for_area(variable_store=vs).sum(axis=1)
+    dfv = pd.read_csv(ds.AREA_CASEFILES['Varsinais-Suomi'], header=0, index_col=0)
+    rows_vs = [[str(d), int(r['dead']), int(r['in_icu']), int(r['in_ward']), int(r['confirmed'])] for d, r in dfv.iterrows()]
+    with open(os.path.join(HERE, '..', '..', 'reina_model_amd', 'data', 'fi_varsinais-suomi.json'), 'w') as f:
+        json.dump(dict(country=v['country'], area_name='Varsinais-Suomi', age_counts=[int(x) for x in ages_vs.values], case_rows=rows_vs,
+                       case_columns=['date', 'dead', 'in_icu', 'in_ward', 'confirmed']), f)
+    print('fi_varsinais-suomi.json: N=%d, %d case rows' % (ages_vs.sum(), len(rows_vs)))
 
 
 CK_EVERY = 15

@@ -430,6 +430,11 @@ def test_turku_override_set_equals_the_references():
         V.copy_variables(override_set='tampere')
     with pytest.raises(KeyError):
         datasets.get_population_for_area('Tampere')
+    # the third area the reference keeps a case file for (AREA_CASEFILES, calc/datasets.py:82-86): a hospital DISTRICT, whose population the
+    # reference sums over its member municipalities (recorded through its own get_population_for_area by make_turku.py)
+    assert int(datasets.get_population_for_area('Varsinais-Suomi').sum()) == 479861
+    vs = V.copy_variables(area_name='Varsinais-Suomi', start_date='2020-03-08')
+    assert datasets.get_initial_population_condition(vs).confirmed_cases == 1
     # Turku's case file feeds the initial condition (calc/datasets.py:138-173): a listed start date, and one it does not list
     v.update(start_date='2020-09-01', incubating_at_simulation_start=150, ill_at_simulation_start=50, recovered_at_simulation_start=1000)
     ipc = datasets.get_initial_population_condition(v)
