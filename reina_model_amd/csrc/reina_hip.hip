@@ -441,6 +441,24 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     SET_LDS_DAY(false);
     SET_LDS_DAY(true);
 #undef SET_LDS_DAY
+    {
+        // k_day addresses v104..v127 by hand (k_contacts.inc): the code object must allocate all 128 registers to every instantiation.
+        // tests/test_abi.py checks that in the disassembly of the build it runs on; this is the check a box without the tests makes
+        // (round-5 verdict: a compiler that stopped honouring the clobber list would hand the kernel fewer registers than it names)
+        const void *day_kernels[6] = {reinterpret_cast<const void *>(k_day<false, false, false>), reinterpret_cast<const void *>(k_day<false, false, true>),
+                                      reinterpret_cast<const void *>(k_day<true, false, false>), reinterpret_cast<const void *>(k_day<true, false, true>),
+                                      reinterpret_cast<const void *>(k_day<false, true, false>), reinterpret_cast<const void *>(k_day<false, true, true>)};
+        for (const void *k : day_kernels) {
+            hipFuncAttributes fa;
+            HIP_CHECK_OR(hipFuncGetAttributes(&fa, k), free_engine(e));
+            if (fa.numRegs != 128 || fa.localSizeBytes != 0) {
+                g_last_error = "k_day was built with " + std::to_string(fa.numRegs) + " VGPRs / " + std::to_string(fa.localSizeBytes) +
+                               " bytes of scratch: it names v104..v127 by hand and needs 128 / 0 (rebuild with the ROCm release the sources were written for)";
+                free_engine(e);
+                return REINA_E_HIP;
+            }
+        }
+    }
     SET_LDS(k_hosp_presort, (int)walk_lds);
     SET_LDS(k_hosp_install, inst_lds);
 #undef SET_LDS
