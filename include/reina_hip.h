@@ -92,10 +92,19 @@ extern "C" {
 #define REINA_GID_SHIFT 27
 #define REINA_GID_INDEX_MASK ((1u << REINA_GID_SHIFT) - 1u)
 #define REINA_GID(shard, index) ((int32_t)(((uint32_t)(shard) << REINA_GID_SHIFT) | (uint32_t)(index)))
-/* an exchange buffer: n_shards segments of (xchg_cap + 1) 64-bit words; segment d of xsend is bound for shard d, segment s
+/* an exchange buffer: n_shards segments of REINA_XCHG_SEG_WORDS 64-bit words; segment d of xsend is bound for shard d, segment s
  * of xrecv came from shard s; word 0 of a segment = its record count (may exceed xchg_cap after an overflow: readers clamp),
- * then the records: [gid : 31 << 32][flags : 5 << 27][index at the receiving shard : 27] (csrc/reina_prims.h: rp_xrec) */
-#define REINA_XCHG_WORDS(n_shards, xchg_cap) ((size_t)(n_shards) * ((size_t)(xchg_cap) + 1u))
+ * then xchg_cap record slots: [gid : 31 << 32][flags : 5 << 27][index at the receiving shard : 27] (csrc/reina_prims.h: rp_xrec),
+ * then -- round 6, ABI 7 -- the TRAILER: what a population under mirror attribution all-reduces for its one pool of beds and ICU
+ * units rides in the mid-day exchange of the contact records instead (one collective less a day): word 0 = the sender's free
+ * beds (low half) and free ICU units (high half) at day open, word 1 = its demand of the day (admission / ICU-transfer requests,
+ * same halves), words 2 .. 2 + R - 1 = the packed maps of its R = hosp_ranges bed / ICU event buckets (the sender's segment of
+ * REINA_EXCHANGE_WORDS' table).  The sender fills the trailer of every peer's segment before the mid-day exchange
+ * (k_hosp_presort), the receiver copies the trailers into its own buffers.pressure behind it (k_remote): every kernel
+ * downstream finds the block as an all-reduce would have left it. */
+#define REINA_XCHG_TRAILER_WORDS(hosp_ranges) (2u + (size_t)(hosp_ranges))
+#define REINA_XCHG_SEG_WORDS(xchg_cap, hosp_ranges) ((size_t)(xchg_cap) + 1u + REINA_XCHG_TRAILER_WORDS(hosp_ranges))
+#define REINA_XCHG_WORDS(n_shards, xchg_cap, hosp_ranges) ((size_t)(n_shards) * REINA_XCHG_SEG_WORDS(xchg_cap, hosp_ranges))
 
 /* per-age counter arrays, Population stats main.pyx:1335-1341 */
 enum {
@@ -144,6 +153,8 @@ enum {
                                                            yet counted into R), word [day & 1] (a diagnostic: rounds 4-5 chose the form of
                                                            k_day's stream by yesterday's count; the launch now does, by population size) */
     REINA_L_POOL = 26,                                  /* exact attribution: nodes of buffers.infectee_pool handed out so far */
+    REINA_L_PRESORT_DONE = 28,                          /* exact attribution: workgroups of k_hosp_presort that have finished today (the last one fills
+                                                           the exchange segments' trailers and resets the word) */
     REINA_L_XCHG_PEAK = 27,                             /* exact attribution: the most records any exchange segment of this shard has held so far
                                                            (against reina_config_t.xchg_cap: how close a run came to problem 106) */
     REINA_L_VACC_CURSOR = 32,                           /* [REINA_MAX_VACCINATIONS] */
@@ -329,8 +340,8 @@ typedef struct {
                                  (person_expose's test, main.pyx:239).  A contact that can transmit looks its target up here --
                                  a table of N / 8 bytes that stays in the 256 MB Infinity Cache -- instead of gathering the
                                  target's hot word from HBM */
-    uint64_t *xsend;          /* [REINA_XCHG_WORDS(n_shards, xchg_cap)] exact attribution: records bound for the other shards */
-    uint64_t *xrecv;          /* [REINA_XCHG_WORDS(n_shards, xchg_cap)] ... and what the all-to-all brought from them */
+    uint64_t *xsend;          /* [REINA_XCHG_WORDS(n_shards, xchg_cap, hosp_ranges)] exact attribution: records bound for the other shards */
+    uint64_t *xrecv;          /* [REINA_XCHG_WORDS(n_shards, xchg_cap, hosp_ranges)] ... and what the all-to-all brought from them */
     uint32_t *infectee_pool;  /* [2 * pool_cap] exact attribution: (infectee gid, next node or -1) of the infectees beyond an
                                  agent's inline slots -- an infectee may live on another shard, so the list cannot be threaded
                                  through the infectees' own records.  (Without exact attribution: any non-null pointers.) */
@@ -416,7 +427,7 @@ typedef int (*reina_allreduce_fn)(const void *sendbuff, void *recvbuff, size_t c
                                   void *comm, void *stream);
 int reina_set_collective(reina_engine_t *e, reina_allreduce_fn allreduce, void *comm);
 /* exact attribution: `alltoall` has the signature of RCCL's ncclAllToAll (sendbuff, recvbuff, count per peer, datatype, comm,
- * stream) and is called as alltoall(xsend, xrecv, xchg_cap + 1, 4 = ncclInt64, comm, stream) on the day stream wherever
+ * stream) and is called as alltoall(xsend, xrecv, REINA_XCHG_SEG_WORDS(xchg_cap, hosp_ranges), 4 = ncclInt64, comm, stream) on the day stream wherever
  * reina_step_phase asks for REINA_X_ALLTOALL. */
 typedef int (*reina_alltoall_fn)(const void *sendbuff, void *recvbuff, size_t count, int datatype, void *comm, void *stream);
 int reina_set_alltoall(reina_engine_t *e, reina_alltoall_fn alltoall, void *comm);
@@ -426,7 +437,8 @@ int reina_set_alltoall(reina_engine_t *e, reina_alltoall_fn alltoall, void *comm
  * every shard's buffers.xsend -> segment (sender's rank) of shard d's buffers.xrecv.
  *   REINA_PH_OPEN      the day's opening: snapshot, imports, test queue, level-0 tracing   -> ALLTOALL (exact, tracing days)
  *   REINA_PH_TRACE     exact, tracing days: the received level-0 requests, level-1 tracing -> ALLTOALL (exact, tracing days)
- *   REINA_PH_MAIN      (the received level-1 requests,) vaccination, the stream + contacts  -> ALLREDUCE (sharded) | ALLTOALL (exact)
+ *   REINA_PH_MAIN      (the received level-1 requests,) vaccination, the stream + contacts  -> ALLREDUCE (mirror attribution) or ALLTOALL
+ *                      (exact: the segments' trailers carry what the all-reduce would -- ABI 7)
  *   REINA_PH_END       cross-shard contacts claim, bed / ICU events, installs                -> ALLTOALL (exact)
  *   REINA_PH_FEEDBACK  exact: the sources of cross-shard infections take their infectees
  * reina_step_day_begin == OPEN + TRACE + MAIN and reina_step_day_end == END + FEEDBACK for a population WITHOUT exact attribution. */

@@ -75,13 +75,15 @@ static int age_of(const Par *e, uint32_t i) {
     return lo;
 }
 
-int par_abi_version(void) { return 6; }
+int par_abi_version(void) { return 7; }
 
 /* ---------------------------------------------------------------- exact attribution: ids and exchange segments */
 static int32_t gid_of(const Par *e, uint32_t i) { return (int32_t)(e->gid_base | i); }
 static int gid_local(const Par *e, int32_t g) { return (int)rp_gid_is_local((uint32_t)g, e->gid_base, e->gid_mask); }
 static uint32_t gid_index(const Par *e, int32_t g) { return (uint32_t)g & e->gid_mask; }
-static uint64_t *xseg(const Par *e, uint64_t *buf, uint32_t shard) { return buf + (size_t)shard * ((size_t)e->cfg.xchg_cap + 1u); }
+static uint64_t *xseg(const Par *e, uint64_t *buf, uint32_t shard) { return buf + (size_t)shard * REINA_XCHG_SEG_WORDS(e->cfg.xchg_cap, e->hosp_ranges); }
+/* the trailer of a segment: what rides behind the records of the mid-day exchange (include/reina_hip.h: REINA_XCHG_TRAILER_WORDS) */
+static uint64_t *xtrailer(const Par *e, uint64_t *buf, uint32_t shard) { return xseg(e, buf, shard) + 1u + e->cfg.xchg_cap; }
 static void xsend_push(Par *e, uint32_t dest, uint64_t rec) {
     uint64_t *seg = xseg(e, e->buf.xsend, dest);
     if (seg[0] >= e->cfg.xchg_cap) {
@@ -1253,10 +1255,36 @@ int par_step_phase(Par *e, const reina_day_t *dp, int phase, void *stream) {
             e->buf.pressure[REINA_PRESSURE_DEMAND_BEDS(e->cfg.shard_rank)] = CTL(e, REINA_L_HOSP_ADMIT);
             e->buf.pressure[REINA_PRESSURE_DEMAND_ICU(e->cfg.shard_rank)] = CTL(e, REINA_L_ICU_ADMIT);
             publish_hospital_maps(e);
+            if (e->exact) {
+                /* exact attribution: the four capacity words and this shard's maps ride in the trailer of every peer's segment of the
+                 * mid-day exchange (no all-reduce) */
+                const uint64_t *maps = exchange_maps(e, e->cfg.shard_rank);
+                for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+                    if (sh == e->cfg.shard_rank) continue;
+                    uint64_t *tr = xtrailer(e, e->buf.xsend, sh);
+                    tr[0] = (uint64_t)(uint32_t)free_beds_open | ((uint64_t)(uint32_t)free_icu_open << 32);
+                    tr[1] = (uint64_t)(uint32_t)CTL(e, REINA_L_HOSP_ADMIT) | ((uint64_t)(uint32_t)CTL(e, REINA_L_ICU_ADMIT) << 32);
+                    for (uint32_t b = 0; b < e->hosp_ranges; b++) tr[2u + b] = maps[b];
+                }
+            }
         }
-        return ((e->cfg.n_shards > 1 || e->coll_fn) ? REINA_X_ALLREDUCE : 0) | (e->exact ? REINA_X_ALLTOALL : 0);
+        if (e->exact) return REINA_X_ALLTOALL;
+        return (e->cfg.n_shards > 1 || e->coll_fn) ? REINA_X_ALLREDUCE : 0;
     }
     case REINA_PH_END:
+        if (e->exact) {
+            /* the trailers the mid-day exchange brought: into the block an all-reduce would have filled */
+            for (uint32_t sh = 0; sh < e->cfg.n_shards; sh++) {
+                if (sh == e->cfg.shard_rank) continue;
+                const uint64_t *tr = xtrailer(e, e->buf.xrecv, sh);
+                e->buf.pressure[REINA_PRESSURE_FREE_BEDS(sh)] = (int32_t)(uint32_t)tr[0];
+                e->buf.pressure[REINA_PRESSURE_FREE_ICU(sh)] = (int32_t)(uint32_t)(tr[0] >> 32);
+                e->buf.pressure[REINA_PRESSURE_DEMAND_BEDS(sh)] = (int32_t)(uint32_t)tr[1];
+                e->buf.pressure[REINA_PRESSURE_DEMAND_ICU(sh)] = (int32_t)(uint32_t)(tr[1] >> 32);
+                uint64_t *maps = exchange_maps(e, sh);
+                for (uint32_t b = 0; b < e->hosp_ranges; b++) maps[b] = tr[2u + b];
+            }
+        }
         run_remote(e, dp);     /* (a stand-in source's infectee-list flag: its word before the day's bed / ICU walk) */
         run_hospital(e, dp);
         run_install(e, dp);
@@ -1306,7 +1334,7 @@ int par_step_day(Par *e, const reina_day_t *dp, void *stream) {
             return REINA_E_INVALID;
         if (rc & REINA_X_ALLTOALL) {
             if (!e->a2a_fn) return REINA_E_NOT_BOUND;   /* exact attribution cannot run without its exchange */
-            if (e->a2a_fn(e->buf.xsend, e->buf.xrecv, (size_t)e->cfg.xchg_cap + 1u, 4, e->a2a_comm, stream) != 0) return REINA_E_INVALID;
+            if (e->a2a_fn(e->buf.xsend, e->buf.xrecv, REINA_XCHG_SEG_WORDS(e->cfg.xchg_cap, e->hosp_ranges), 4, e->a2a_comm, stream) != 0) return REINA_E_INVALID;
         }
     }
     return 0;

@@ -223,7 +223,7 @@ static void count_row_for(float nr_contacts, uint32_t *thr, uint8_t *guide) {
 
 extern "C" {
 
-int reina_abi_version(void) { return 6; }
+int reina_abi_version(void) { return 7; }
 
 #ifdef REINA_ABLATE
 int reina_debug_ablate(uint32_t bits) {   // diagnostic builds only (tools/ablate_day.py)
@@ -404,6 +404,7 @@ int reina_create(const reina_config_t *cfg, const reina_disease_t *disease, rein
     e->h_params.max_queue = cfg->max_queue;
     e->h_params.max_hosp_events = cfg->max_hosp_events > REINA_MAX_HOSP_EVENTS ? cfg->max_hosp_events : REINA_MAX_HOSP_EVENTS;
     e->h_params.hosp_ranges = cfg->hosp_ranges ? cfg->hosp_ranges : REINA_HOSP_RANGES(cfg->n_agents);
+    e->h_params.xchg_stride = (uint32_t)REINA_XCHG_SEG_WORDS(e->h_params.xchg_cap, e->h_params.hosp_ranges);   // (exact attribution: a segment = count + records + trailer)
     if (e->h_params.hosp_ranges < 16 || e->h_params.hosp_ranges > REINA_HOSP_MAX_RANGES || (e->h_params.hosp_ranges & (e->h_params.hosp_ranges - 1))) {
         g_last_error = "hosp_ranges must be a power of two in [16, REINA_HOSP_MAX_RANGES]";
         delete e;
@@ -1089,7 +1090,11 @@ int reina_step_phase(reina_engine_t *e, const reina_day_t *day, int phase, void 
     case REINA_PH_MAIN:
         rc = launch_day_main(e, e->d_ref, 1, *day, s);
         // (a single shard with a collective set exchanges too: the one-GPU box exercises the call)
-        return rc ? rc : (((e->cfg.n_shards > 1 || e->coll_fn) ? REINA_X_ALLREDUCE : 0) | (e->exact ? REINA_X_ALLTOALL : 0));
+        // exact attribution (round 6, ABI 7): what the all-reduce carries -- the shards' capacity words and event maps -- rides in the
+        // trailers of the contact records' segments: ONE collective here, not two
+        if (rc) return rc;
+        if (e->exact) return REINA_X_ALLTOALL;
+        return (e->cfg.n_shards > 1 || e->coll_fn) ? REINA_X_ALLREDUCE : 0;
     case REINA_PH_END:
         rc = launch_day_end(e, e->d_ref, 1, *day, s);
         return rc ? rc : (e->exact ? REINA_X_ALLTOALL : 0);
@@ -1156,7 +1161,7 @@ int reina_step_day(reina_engine_t *e, const reina_day_t *day, void *stream) {
                 g_last_error = "exact attribution: no all-to-all set (reina_set_alltoall) -- step the day by reina_step_phase and exchange buffers.xsend / xrecv yourself";
                 return REINA_E_NOT_BOUND;
             }
-            const int r = e->a2a_fn(e->buf.xsend, e->buf.xrecv, (size_t)e->cfg.xchg_cap + 1u, 4 /* ncclInt64 */, e->a2a_comm, stream);
+            const int r = e->a2a_fn(e->buf.xsend, e->buf.xrecv, (size_t)e->h_params.xchg_stride, 4 /* ncclInt64 */, e->a2a_comm, stream);
             if (r != 0) {
                 g_last_error = "all-to-all failed with code " + std::to_string(r);
                 return REINA_E_HIP;

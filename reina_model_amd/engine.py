@@ -47,7 +47,7 @@ L_POOL = 26        # control word (exact attribution): nodes of infectee_pool ha
 L_XCHG_PEAK = 27   # control word (exact attribution): the fullest any exchange segment has been (against Config.xchg_cap)
 L_HOSP_PEAK = 12   # control word: bed / ICU event count of the busiest day on which the events' order mattered
 MAX_DAYS = 4096    # reina_day_t.day < MAX_DAYS (include/reina_hip.h: REINA_MAX_DAYS)
-ABI_VERSION = 6   # (round 6: REINA_PK_SMALL_DAY, the one-launch day of a small population)  reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays; round 4: the two per-agent bit planes; round 5: exact cross-shard attribution -- exchange buffers, infectee pool, reina_step_phase)
+ABI_VERSION = 7   # (round 6: 6 = REINA_PK_SMALL_DAY, the one-launch day of a small population; 7 = exchange segments carry a trailer, exact attribution's MAIN phase asks for ONE collective)  reina_abi_version(): struct layouts of include/reina_hip.h (round 3: 32-byte cold record + inline infectee slots instead of seven per-agent arrays; round 4: the two per-agent bit planes; round 5: exact cross-shard attribution -- exchange buffers, infectee pool, reina_step_phase)
 INLINE_INFECTEES = 8   # REINA_INLINE_INFECTEES
 COLD_WORDS = 8         # sizeof(reina_cold_t) / 4: claim (2 words), infector, n_infected, onset_days, vacc_day, first_infectee, next_sibling
 COLD_FIELDS = dict(infector=2, n_infected=3, onset_days=4, vacc_day=5, first_infectee=6, next_sibling=7)   # word of each 32-bit field
@@ -186,10 +186,11 @@ def exchange_words(n_shards, ranges):
     return PRESSURE_WORDS + (n_shards * 2 * ranges if n_shards > 1 else 0)
 
 
-def xchg_words(n_shards, xchg_cap):
+def xchg_words(n_shards, xchg_cap, ranges):
     """include/reina_hip.h: REINA_XCHG_WORDS -- 64-bit words of buffers.xsend / xrecv (exact attribution): per peer shard a
-    count word and xchg_cap records"""
-    return n_shards * (xchg_cap + 1)
+    count word, xchg_cap records and the trailer (two capacity words + the maps of the sender's `ranges` event buckets: what rides
+    in the mid-day exchange instead of an all-reduce, ABI 7)"""
+    return n_shards * (xchg_cap + 1 + 2 + ranges)
 
 
 def bind_abi(lib, prefix):
@@ -366,8 +367,8 @@ class Engine:
             active_bits=a.zeros(bits_words(n), np.uint32), infected_bits=a.zeros(bits_words(n), np.uint32),
             # exact cross-shard attribution: the records bound for / received from the other shards, and the overflow nodes
             # of the infectee lists (otherwise placeholders: the library wants non-null pointers)
-            xsend=a.zeros(xchg_words(config.n_shards, config.xchg_cap) if config.exact_attribution else 2, np.uint64),
-            xrecv=a.zeros(xchg_words(config.n_shards, config.xchg_cap) if config.exact_attribution else 2, np.uint64),
+            xsend=a.zeros(xchg_words(config.n_shards, config.xchg_cap, config.hosp_ranges or hosp_ranges(n)) if config.exact_attribution else 2, np.uint64),
+            xrecv=a.zeros(xchg_words(config.n_shards, config.xchg_cap, config.hosp_ranges or hosp_ranges(n)) if config.exact_attribution else 2, np.uint64),
             infectee_pool=a.zeros(2 * config.pool_cap if config.exact_attribution else 2, np.uint32),
         )
         bufs = Buffers(**{k: a.ptr(v) for k, v in self.tensors.items()})

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), name
     f = eng.bind_abi(lib, 'reina_')
-    assert f["abi_version"]() == eng.ABI_VERSION == 6
+    assert f["abi_version"]() == eng.ABI_VERSION == 7
 
 
 def test_struct_layouts_match_the_header_sizes():
