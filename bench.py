@@ -671,7 +671,7 @@ def main():
     ap.add_argument('--no-strong', action='store_true')
     ap.add_argument('--attribution', default='mirror', choices=('mirror', 'exact'),
                     help='N > 1: cross-shard infector links of the headline, `large` and `strong` runs -- mirror: stand-in infectors, ONE '
-                         'all-reduce per day (north_star\'s exchange); exact: true links, three to five exchanges per day (SURVEY 8 f-4). '
+                         'all-reduce per day (north_star\'s exchange); exact: true links, two exchanges per day, four on contact-tracing days (SURVEY 8 f-4). '
                          '`strong` carries the other mode\'s figure beside it')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-sizes', action='store_true', help='skip the full_scenario object')
@@ -798,7 +798,7 @@ def main():
                       'the launches sharding adds, `collective` is the event-timed cost of RCCL itself per exchange point',
         }
         # the other attribution mode on the same ranks (exact: the true links, contact / feedback / tracing records through
-        # ncclAllToAll -- three to five exchanges a day instead of one)
+        # ncclAllToAll -- two exchanges a day, four on contact-tracing days, instead of one)
         other = 'exact' if a.attribution == 'mirror' else 'mirror'
         try:
             ro = run_gpu(vs_, ages_s, a.seed, 365, 0, device, dist, preheat=0, stride=16, preheat_runs=0, attribution=other)
@@ -824,7 +824,7 @@ def main():
             'config': {'workload': workload, 'agents_total': total_agents, **({'attribution': a.attribution} if world > 1 else {}),
                        'parallelism': 'single GPU' if world == 1 else (
                            'agents sharded x%d, one RCCL all-reduce per day (infection pressure + the shards\' bed / ICU event maps)' % world if a.attribution == 'mirror' else
-                           'agents sharded x%d, exact attribution: one RCCL all-reduce + two ncclAllToAll per day (four on contact-tracing days)' % world),
+                           'agents sharded x%d, exact attribution: two ncclAllToAll per day (four on contact-tracing days), the capacity words and event maps in their trailers' % world),
                        'final_all_infected': res['stats']['final_all_infected'], 'peak_infected_in_window': res['stats']['peak_infected']},
             'roofline': roofline_obj(n_agents, res, a.steps, stride, traffic_key),
             'notes': ['the timed region covers host planning, launches, every kernel of the days and the read-back of their history rows; '

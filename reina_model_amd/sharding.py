@@ -119,7 +119,8 @@ class DirectRccl:
 
 # Cross-shard infector links: the ONE place the default is decided.  'exact': the true
 # infector of every cross-shard infection, as in the reference (main.pyx:219-233) -- contact / feedback / tracing records through
-# all-to-all segments, three to five collectives a day; 'mirror': stand-in infectors, ONE all-reduce a day (north_star's exchange).
+# all-to-all segments, two collectives a day (four on contact-tracing days; round 6: the shards' capacity words and event maps ride in the
+# segments' trailers, no all-reduce); 'mirror': stand-in infectors, ONE all-reduce a day (north_star's exchange).
 # The library's comm objects default to it; model.Context reads the comm's `attribution` (a comm object without one gets it too and
 # must then provide all_to_all: checked at construction); bench.py --gpus N measures 'mirror' unless told otherwise and labels
 # its line with the mode it ran (config.attribution) -- the one-collective day is what BASELINE.json's north_star describes.
