@@ -63,7 +63,10 @@ for case in range(n):
     for kind, seed0 in (('random', 100000), ('extreme', 200000)):
         rng = np.random.default_rng(seed0 + OFF + case)
         v, ages, days, ivs, ipc = T._random_scenario(rng)
-        os.environ['REINA_DAY_MODE'] = ('dense', 'sparse')[(case + (kind == 'extreme')) % 2]   # (round 4: both forms of k_day's stream)
+        if os.environ.get('REINA_FUSED_DAY') == '1':
+            os.environ.pop('REINA_DAY_MODE', None)   # (round 6: the one-launch form of a small population's days is taken only when no form of k_day is forced)
+        else:
+            os.environ['REINA_DAY_MODE'] = ('dense', 'sparse')[(case + (kind == 'extreme')) % 2]   # (round 4: both forms of k_day's stream)
         try:
             if kind == 'extreme':
                 total = int(rng.integers(600, 6000))
