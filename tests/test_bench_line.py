@@ -115,3 +115,28 @@ def test_recorded_line_of_this_round_parses_and_fits():
     assert len(text) < 8000 and len(text.splitlines()) == 1
     line = json.loads(text)
     assert line['roofline']['frac'] > 0 and line['cpu_baseline']['value'] > 0 and line['dtype'] == 'u32'
+
+
+def test_a_multi_gpu_line_fits_too():
+    """`bench.py --gpus N` adds `large`, `strong` (with the other attribution mode beside it) and a distributed `ensemble` to the object:
+    the digest keeps them under the same cap (verdict r05 item 9: "keep the --gpus 8 line under item 1's size cap too")"""
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'bench_detail.json')))
+    fs = full['full_scenario']['100000000']
+    out = {k: v for k, v in full.items() if k not in ('full_scenario', 'cpu_baseline', 'value_warm', 'ms_per_step_warm', 'headline_is')}
+    out['n_gpus'] = 8
+    out['config'] = dict(out['config'], attribution='mirror', rccl_world=8, collective='ncclAllReduce queued on the day stream (own RCCL communicator)',
+                         parallelism='agents sharded x8, one RCCL all-reduce per day (infection pressure + the shards\' bed / ICU event maps)')
+    roof = json.loads(json.dumps(fs['roofline']))
+    roof['kernels']['k_remote'] = dict(avg_launch_us=12.9, timed_launches=23)
+    roof['kernels']['collective'] = dict(avg_launch_us=31.0, timed_launches=23)
+    out['large'] = dict(workload='synthetic 400000000 agents (50000000 per GPU, BASELINE configs[3] shape), default scenario scaled, 365 days',
+                        value=1.0e12, unit='agent-days/s', ms_per_step=0.146, roofline=roof, final_all_infected=1)
+    out['strong'] = dict(workload='synthetic 100000000 agents in total', scaling='strong', attribution='mirror', value=7.0e11, unit='agent-days/s',
+                         ms_per_step=0.052, rccl_world=8, roofline=roof, final_all_infected=1, expect='x' * 700,
+                         exact=dict(value=6.0e11, ms_per_step=0.061, kernels={'k_day': 50.0}, exchange_segment_fill={'peak_records': 1, 'capacity': 2}))
+    line = bench.compact_line(out)
+    text = json.dumps(line, separators=(',', ':'))
+    assert len(text) < bench.LINE_LIMIT and not line.get('truncated')
+    assert line['n_gpus'] == 8 and line['config']['attribution'] == 'mirror' and line['config']['rccl_world'] == 8
+    assert line['large']['value'] == 1.0e12 and line['large']['kernel_us']['collective'] == 31.0 and line['large']['roofline']['frac'] > 0
+    assert line['strong']['exact']['value'] == 6.0e11 and line['strong']['scaling'] == 'strong' and 'cpu_baseline' not in line
