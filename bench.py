@@ -595,7 +595,18 @@ def ensemble_line(seeds, days, device, dist=None):
     del warm
     # (and the group kernels' first launches -- the runtime loads a kernel's code when it is first launched -- by a warm-up group
     # of two throw-away members over five days: the ensemble's counterpart of the headline's warm-up steps)
-    pre = [simulation.make_context(v, age_counts=ages, seed=90 + k, device=device) for k in range(2)]
+    # (round 6: a two-member group streams the hot words -- 1.6 tiles per wave --, the timed group of `seeds` members the bit planes: another
+    # instantiation of k_day, whose first launch cost 1.1 ms inside the timed region on some boxes -- its mean over 23 timed launches read
+    # 154 us there and 107 elsewhere.  The warm-up members are made with the sparse form forced, so the kernels it loads are the timed ones.)
+    prev_mode = os.environ.get('REINA_DAY_MODE')
+    os.environ['REINA_DAY_MODE'] = 'sparse'
+    try:
+        pre = [simulation.make_context(v, age_counts=ages, seed=90 + k, device=device) for k in range(2)]
+    finally:
+        if prev_mode is None:
+            os.environ.pop('REINA_DAY_MODE', None)
+        else:
+            os.environ['REINA_DAY_MODE'] = prev_mode
     ensemble.run_group_plan(pre, pre[0].make_plan(5))
     del pre
     if dist is not None:
