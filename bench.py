@@ -609,15 +609,24 @@ def ensemble_line(seeds, days, device, dist=None):
             os.environ['REINA_DAY_MODE'] = prev_mode
     ensemble.run_group_plan(pre, pre[0].make_plan(5))
     del pre
+    # (round 6: as in run_gpu -- the Contexts of the runs before this one sit in reference cycles and die when the collector gets to them,
+    # destroying their engines with synchronising calls; inside the timed region that was 20-25 ms of a 80 ms ensemble on every box:
+    # tools/ens_first_run.py measures 78.6 ms for this very sequence with nothing to collect, the line read 104)
+    import gc
+    gc.collect()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    hist = ensemble.run_group_plan(members, plan)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        hist = ensemble.run_group_plan(members, plan)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     prof = members[0].engine.profile_read_kernels()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
