@@ -31,6 +31,12 @@ def run_group_plan(contexts, plan, record_history=True, member_plans=None):
     differ in the VALUES of their mobility limits / mask shares only, so they share the day descriptors
     of `plan` while every member gets its own contact tables at each table change."""
     from . import engine as _eng
+    import os as _os, time as _time
+    _T = [] if _os.environ.get('REINA_ENS_TIMING') else None   # (diagnostic: where a group run's wall time goes, tools/ens_first_run2.py)
+    def _t(name):
+        if _T is not None:
+            _T.append((name, _time.perf_counter()))
+    _t('start')
     group = _eng.EngineGroup([c.engine for c in contexts])
     a = group.alloc
     days = plan['days']
@@ -48,12 +54,14 @@ def run_group_plan(contexts, plan, record_history=True, member_plans=None):
         ptrs = [a.ptr(hist) + row * (m * days + done) for m in range(K)] if record_history else None
         group.run_day_array(arr, n, ptrs)
         done += n
+    _t('issued')
     for m, c in enumerate(contexts):
         c.mobility_history = (member_plans[m] if member_plans is not None else plan)['mobility_history']
         c.day = plan['start_day'] + days
     out = None
     if record_history:
         out = a.to_host(hist).reshape(K, days, _eng.COUNTER_WORDS)
+    _t('history on the host')
     torch = getattr(a, 'torch', None)
     if torch is not None:
         # the members' final counter blocks (the problem word among them) in one copy instead of one per member (4 ms for 128)
@@ -63,7 +71,11 @@ def run_group_plan(contexts, plan, record_history=True, member_plans=None):
     else:
         for c in contexts:
             c._raise_on_problem(c.engine.read_counters())
+    _t('final counters')
     group.close()
+    _t('closed')
+    if _T is not None:
+        print('run_group_plan: ' + ' | '.join('%s %.1f ms' % (n, (t - _T[k][1]) * 1e3) for k, (n, t) in enumerate(_T[1:])), flush=True)
     return out
 
 

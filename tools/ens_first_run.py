@@ -10,9 +10,13 @@ seeds, days = 128, 365
 planner = simulation.make_context(v, age_counts=ages, seed=0)
 plan = planner.make_plan(days)
 members = [simulation.make_context(v, age_counts=ages, seed=100 + k) for k in range(seeds)]
+if 'profile' in sys.argv:
+    members[0].engine.profile_enable(16)
 warm = torch.empty(seeds * days * _eng.COUNTER_WORDS, dtype=torch.int32, pin_memory=True); del warm
 os.environ['REINA_DAY_MODE'] = 'sparse'
 pre = [simulation.make_context(v, age_counts=ages, seed=90 + k) for k in range(2)]
+if 'warmprofile' in sys.argv:
+    pre[0].engine.profile_enable(1)
 os.environ.pop('REINA_DAY_MODE')
 ensemble.run_group_plan(pre, pre[0].make_plan(5)); del pre
 for rep in range(3):
