@@ -311,12 +311,10 @@ class TorchAllocator:
         # (PyTorch's caching host allocator keeps the pinned block for the next run.)
         nbytes = t.numel() * t.element_size()
         if (1 << 18) <= nbytes <= (1 << 29):
-            if nbytes >= (1 << 26):
-                # (round 6: a large read-back -- an engine group's 325 MB of history -- WAITS for the stream first and asks for its page-locked
-                # block afterwards: requested while the group's kernels were still running, the block cost 22 ms more -- 106 ms against
-                # 83 for a 128-member year, tools/ens_first_run2.py; PyTorch's caching host allocator takes the slow path while the
-                # device is busy)
-                self.torch.cuda.current_stream(self.device).synchronize()
+            # (round 6: the read-back WAITS for the stream first and asks for its page-locked block afterwards: requested while an
+            # engine group's kernels were still running, the 325 MB block of its history cost 22 ms more -- 106 ms against 83 for a
+            # 128-member year, tools/ens_first_run2.py; the copy below waits for the stream anyway)
+            self.torch.cuda.current_stream(self.device).synchronize()
             h = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
             h.copy_(t, non_blocking=True)
             self.torch.cuda.current_stream(self.device).synchronize()
