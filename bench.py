@@ -106,27 +106,6 @@ def stride_for(steps, time_every):
     return 4 if steps < 16 else 8 if steps < 64 else 16
 
 
-def _spin_gpu(device, ms=12.0):
-    """A burst of plain device work, queued and not waited for, right in front of a measured region.  The throw-away preheat runs
-    bring the GPU out of its idle power state, but the measured simulation is constructed AFTER them -- some 50-100 ms of host work
-    during which the device idles again -- and a timed window that opens on a device ramping up can catch a stall of about a
-    millisecond: one 20-step window in fifteen read 0.094 ms a step instead of 0.036, and single launches of the ensemble's timed
-    year measured 1.1 ms too long (round 6, profiles/r06_evidence).  The burst keeps the device busy until the warm-up steps start."""
-    import torch
-    if os.environ.get('REINA_BENCH_NO_SPIN'):   # (A/B handle)
-        return None
-    x = torch.empty(32 << 20, dtype=torch.int32, device=device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(8):
-        x.add_(1)
-    torch.cuda.synchronize()
-    per = max((time.perf_counter() - t0) / 8, 1e-6)
-    for _ in range(max(8, int(ms * 1e-3 / per))):
-        x.add_(1)
-    return x   # (kept alive by the caller until the region is over: freeing it would synchronise)
-
-
 def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, stride=16, preheat_runs=2, attribution='mirror', day_only=False):
     import numpy as np
     import torch
@@ -158,7 +137,6 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
     # (day_only: the short cold window times its dominant kernel alone -- a timestamped dispatch costs 5.5 us of a 740 us window; the
     # other kernels' figures come from the warm window beside it)
     ctx.engine.profile_enable(-stride if day_only else stride)
-    spin = _spin_gpu(device)   # (the device busy until the warm-up steps start: see _spin_gpu)
     if warmup:
         ctx.run(warmup, record_history=False)
     ctx.synchronize()
@@ -178,7 +156,6 @@ def run_gpu(variables, ages, seed, steps, warmup, device, dist=None, preheat=0, 
         gc.enable()
     prof = ctx.engine.profile_read_kernels()
     ctx.engine.profile_enable(False)
-    del spin
     A = eng.MAX_AGES
 
     def tot(name):
@@ -637,7 +614,6 @@ def ensemble_line(seeds, days, device, dist=None):
     # tools/ens_first_run.py measures 78.6 ms for this very sequence with nothing to collect, the line read 104)
     import gc
     gc.collect()
-    spin = _spin_gpu(device)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -651,7 +627,6 @@ def ensemble_line(seeds, days, device, dist=None):
         dt = time.perf_counter() - t0
     finally:
         gc.enable()
-    del spin
     prof = members[0].engine.profile_read_kernels()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
